@@ -1,0 +1,201 @@
+"""Pins the CPU oracle (oracle/sparse_ref.c) -- "parity unpinned" by the reference,
+pinned here by brute-force enumeration and dense equivalence."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_oracle as so
+from oracle import dense_equiv as de
+from uresnet_pytorch_amd.iotools.synthetic import generate_event
+
+TOL = 1e-5  # relative (norm-wise) fp32 tolerance, BASELINE.json north_star
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def small_cloud(seed, S=24, n=400, nbatch=2, dup=True):
+    rng = np.random.default_rng(seed)
+    cs = []
+    for b in range(nbatch):
+        c, _, _ = generate_event(seed * 10 + b, S, n)
+        cs.append(np.concatenate([c, np.full((len(c), 1), b, np.int32)], 1))
+    c = np.concatenate(cs, 0)
+    if dup:  # duplicated rows (InputLayer mode 3 sums them)
+        c = np.concatenate([c, c[rng.integers(0, len(c), 37)]], 0)
+        c = c[rng.permutation(len(c))]
+    f = rng.normal(size=(len(c), 1)).astype(np.float32)
+    return c.astype(np.int32), f
+
+
+def test_sites_build_vs_brute(oracle_lib):
+    c, f = small_cloud(1)
+    r2s, sc, sf = so.sites_build(c, f, mode=3)
+    br2s, bsc = de.brute_sites(c)
+    assert np.array_equal(r2s, br2s) and np.array_equal(sc, bsc)
+    ref = np.zeros((len(sc), 1), np.float64)
+    np.add.at(ref, r2s, f.astype(np.float64))
+    assert rel(sf, ref) < TOL
+
+
+def test_sites_build_edge_cases(oracle_lib):
+    r2s, sc, sf = so.sites_build(np.zeros((0, 4), np.int32), np.zeros((0, 1), np.float32))
+    assert len(r2s) == 0 and len(sc) == 0
+    c = np.array([[3, 3, 3, 0]] * 5, np.int32)  # one site, 5 duplicates
+    f = np.arange(5, dtype=np.float32)[:, None]
+    r2s, sc, sf = so.sites_build(c, f, mode=3)
+    assert len(sc) == 1 and sf[0, 0] == 10.0 and np.all(r2s == 0)
+    assert so.sites_build(c, f, mode=2)[2][0, 0] == 0.0   # keep first
+    assert so.sites_build(c, f, mode=1)[2][0, 0] == 4.0   # keep last
+    assert so.sites_build(c, f, mode=4)[2][0, 0] == 2.0   # mean
+
+
+def test_rulebook_subm_vs_brute(oracle_lib):
+    S = 24
+    c, f = small_cloud(2, S)
+    _, sc, _ = so.sites_build(c, f)
+    nbr, R = so.rulebook_subm(sc, S)
+    t = so.canonical_triples(nbr)
+    bt = de.brute_subm_triples(sc, S)
+    assert R == len(bt) and np.array_equal(t, bt)
+    # centre offset is the identity, table is mirror-symmetric
+    assert np.array_equal(nbr[13], np.arange(len(sc)))
+    assert np.array_equal(so.invert_table(nbr, len(sc)), nbr[::-1])
+
+
+def test_rulebook_border(oracle_lib):
+    # sites on the volume border: no wrap-around through the 16-bit key fields
+    S = 8
+    sc = np.array([[0, 0, 0, 0], [7, 7, 7, 0], [0, 0, 1, 0], [7, 7, 6, 1]], np.int32)
+    nbr, R = so.rulebook_subm(sc, S)
+    assert np.array_equal(so.canonical_triples(nbr), de.brute_subm_triples(sc, S))
+
+
+def test_level_down_vs_brute(oracle_lib):
+    c, f = small_cloud(3)
+    _, sc, _ = so.sites_build(c, f)
+    cc, parent, off, chd, up = so.level_down(sc)
+    bcc, bparent, boff = de.brute_down(sc)
+    assert np.array_equal(cc, bcc) and np.array_equal(parent, bparent) and np.array_equal(off, boff)
+    for i in range(len(sc)):
+        assert chd[off[i], parent[i]] == i and up[off[i], i] == parent[i]
+    assert (chd >= 0).sum() == len(sc) and (up >= 0).sum() == len(sc)
+
+
+@pytest.mark.parametrize('cin,cout', [(1, 16), (16, 32), (48, 16)])
+def test_subm_conv_dense_equivalence(oracle_lib, cin, cout):
+    S, nb = 16, 2
+    c, _ = small_cloud(4, S, 300, nb, dup=False)
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(len(c), cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    nbr, _ = so.rulebook_subm(c, S)
+    y = so.conv_fwd(x, W, nbr)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    yd = de.sample(torch.nn.functional.conv3d(
+        _densify_t(c, xt, S, nb), _subm_w(Wt), padding=1), c)
+    assert rel(y, yd.detach().numpy()) < TOL
+    dy = rng.normal(size=y.shape).astype(np.float32)
+    yd.backward(torch.tensor(dy, dtype=torch.float64))
+    dx, dW = so.conv_bwd(x, W, nbr, dy)
+    assert rel(dx, xt.grad.numpy()) < TOL and rel(dW, Wt.grad.numpy()) < TOL
+
+
+def _densify_t(coords, xt, S, nb):
+    # differentiable densify: (N,C) rows -> dense volume (B,C,S,S,S)
+    c = torch.as_tensor(coords, dtype=torch.long)
+    B, C = nb, xt.shape[1]
+    flat = ((c[:, 3] * S + c[:, 0]) * S + c[:, 1]) * S + c[:, 2]
+    out = torch.zeros(B * S * S * S, C, dtype=torch.float64).index_add(0, flat, xt)
+    return out.reshape(B, S, S, S, C).permute(0, 4, 1, 2, 3)
+
+
+def _subm_w(Wt):
+    return Wt.reshape(3, 3, 3, Wt.shape[1], Wt.shape[2]).permute(4, 3, 0, 1, 2)
+
+
+def test_down_up_conv_dense_equivalence(oracle_lib):
+    S, nb, cin, cout = 16, 2, 16, 32
+    c, _ = small_cloud(5, S, 300, nb, dup=False)
+    rng = np.random.default_rng(1)
+    cc, parent, off, chd, up = so.level_down(c)
+    x = rng.normal(size=(len(c), cin)).astype(np.float32)
+    Wd = (rng.normal(size=(8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)
+    y = so.conv_fwd(x, Wd, chd)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = torch.tensor(Wd, dtype=torch.float64, requires_grad=True)
+    wd = Wt.reshape(2, 2, 2, cin, cout).permute(4, 3, 0, 1, 2)
+    yd = de.sample(torch.nn.functional.conv3d(_densify_t(c, xt, S, nb), wd, stride=2), cc)
+    assert rel(y, yd.detach().numpy()) < TOL
+    dy = rng.normal(size=y.shape).astype(np.float32)
+    yd.backward(torch.tensor(dy, dtype=torch.float64))
+    dx, dW = so.conv_bwd(x, Wd, chd, dy, inv=up)
+    assert rel(dx, xt.grad.numpy()) < TOL and rel(dW, Wt.grad.numpy()) < TOL
+    # deconvolution coarse -> fine
+    z = rng.normal(size=(len(cc), cout)).astype(np.float32)
+    Wu = (rng.normal(size=(8, cout, cin)) / np.sqrt(8 * cout)).astype(np.float32)
+    u = so.conv_fwd(z, Wu, up)
+    zt = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+    Wut = torch.tensor(Wu, dtype=torch.float64, requires_grad=True)
+    wu = Wut.reshape(2, 2, 2, cout, cin).permute(3, 4, 0, 1, 2)
+    ud = de.sample(torch.nn.functional.conv_transpose3d(_densify_t(cc, zt, S // 2, nb), wu, stride=2), c)
+    assert rel(u, ud.detach().numpy()) < TOL
+    du = rng.normal(size=u.shape).astype(np.float32)
+    ud.backward(torch.tensor(du, dtype=torch.float64))
+    dz, dWu = so.conv_bwd(z, Wu, up, du, inv=chd)
+    assert rel(dz, zt.grad.numpy()) < TOL and rel(dWu, Wut.grad.numpy()) < TOL
+
+
+def test_bn_relu_vs_torch(oracle_lib):
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(257, 48)).astype(np.float32) * 2 + 0.3
+    g = (1 + 0.1 * rng.normal(size=48)).astype(np.float32)
+    b = (0.1 * rng.normal(size=48)).astype(np.float32)
+    y, mean, invstd = so.bn_relu_fwd(x, g, b, True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(g, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    yt = torch.relu(torch.nn.functional.batch_norm(xt, None, None, gt, bt, True, 0.0, so.BN_EPS))
+    assert rel(y, yt.detach().numpy()) < TOL
+    dy = rng.normal(size=y.shape).astype(np.float32)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    dx, dg, db = so.bn_relu_bwd(x, y, dy, g, mean, invstd, True)
+    assert rel(dx, xt.grad.numpy()) < TOL and rel(dg, gt.grad.numpy()) < TOL and rel(db, bt.grad.numpy()) < TOL
+
+
+def test_network_vs_torch_float64(oracle_lib):
+    """Whole-network forward/backward of the oracle against an independent float64
+    torch re-expression with autograd."""
+    S, m, L, nc = 32, 4, 3, 5
+    c, f = small_cloud(6, S, 500, 2, dup=True)
+    pc = np.concatenate([c.astype(np.float32), f], 1)
+    lab = np.random.default_rng(3).integers(0, nc, size=(len(pc), 1)).astype(np.float32)
+    P = so.init_params(m, L, nc, seed=1)
+    net = so.SparseUResNetOracle(P, m, L, nc, S)
+    logits = net.forward(pc)
+    loss, acc, dl = so.segmentation_loss(logits, pc, lab)
+    G, dfeat = net.backward(dl)
+    lt, Pt, ft = de.torch_network(P, net.geo, m, L, 2, so.BN_EPS)
+    assert rel(logits, lt.detach().numpy()) < TOL
+    bid = torch.tensor(pc[:, 3]); labt = torch.tensor(lab[:, 0]).long()
+    tl = 0
+    for b in bid.unique():
+        mk = bid == b
+        tl = tl + torch.nn.functional.cross_entropy(lt[mk], labt[mk], reduction='none').mean()
+    assert abs(loss - tl.item()) < 1e-5 * max(1, abs(tl.item()))
+    tl.backward()
+    assert set(G.keys()) == set(P.keys())
+    for k in P:
+        assert rel(G[k], Pt[k].grad.numpy()) < 2e-5, k
+    assert rel(dfeat, ft.grad.numpy()) < 2e-5
+
+
+def test_param_specs_counts():
+    specs = so.param_specs(16, 5, 5)
+    total = sum(int(np.prod(s[1])) for s in specs)
+    assert total == 2741477
+    assert sum(1 for s in specs if s[2] == 'bn_w') == 45
+    assert sum(1 for s in specs if s[1][0] == 27) == 37
