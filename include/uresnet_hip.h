@@ -1,0 +1,131 @@
+/*
+ * uresnet_hip.h -- C ABI of liburesnet_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the U-ResNet sparse/dense 3-D convolution forward+backward
+ * path of Temigo/uresnet_pytorch.  The reference exposes no FFI of its own: its
+ * operator surface for this path is the Python nn.Module API
+ * (reference uresnet/models/uresnet_sparse.py:7-37, uresnet/trainval.py:139-146),
+ * and all sparse arithmetic is reached through `sparseconvnet` call sites.  Each
+ * entry point below names the reference call site whose native work it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the
+ *     caller (PyTorch's caching allocator) and borrowed for the duration of the call;
+ *   - every launch goes on the hipStream_t passed as `stream` (void*); the library
+ *     never synchronises the device and never allocates device memory;
+ *   - return 0 on success, a negative URN_E* code otherwise, message through
+ *     urn_last_error() (thread-local); nothing throws or aborts across the ABI;
+ *   - coords rows are (x, y, z, batch) int32; gather tables are [K][ld] int32 with
+ *     -1 = no active neighbour; feature matrices are row-major (N, C) fp32;
+ *   - site counts produced on the device live in int32 device words so that the
+ *     whole integer phase runs without a host round trip; kernels take
+ *     (n_dev, n_cap): n_dev may be NULL, then n_cap is the exact count.
+ */
+#ifndef URESNET_HIP_H
+#define URESNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URN_OK 0
+#define URN_EINVAL (-1)       /* bad argument (shape, alignment, null) */
+#define URN_EHIP (-2)         /* a HIP runtime call failed */
+#define URN_EUNSUPPORTED (-3) /* shape outside what the kernels were built for */
+
+int urn_version(void);
+const char *urn_last_error(void);
+
+/* ------------------------------------------------------------------ integer phase
+ * Hash tables: `hcap` slots (power of two, from urn_hash_capacity), laid out as
+ * keys uint64[hcap] | first int32[hcap] | site int32[hcap]; the caller hands one
+ * buffer of urn_hash_bytes(hcap) bytes and clears it with urn_hash_clear. */
+int64_t urn_hash_capacity(int64_t n_rows);
+int64_t urn_hash_bytes(int64_t hcap);
+int64_t urn_unique_scratch_bytes(int64_t n_rows);
+int urn_hash_clear(void *hash, int64_t bytes, void *stream);
+
+/* scn.InputLayer(dimension, SPATIAL_SIZE, mode=3)  (reference uresnet_sparse.py:20,33-35):
+ * active sites in first-occurrence order.  row2site[n], site_coords[n_cap][4],
+ * n_active = device int32.  `hash` must be cleared; afterwards it maps coord -> site. */
+int urn_sites_build(const int32_t *coords, int64_t n, int spatial, void *hash, int64_t hcap,
+                    void *scratch, int64_t scratch_bytes, int32_t *row2site,
+                    int32_t *site_coords, int32_t *n_active, void *stream);
+
+/* InputLayer feature merge: site_feats[s,:] = sum (mode 3) of feats[i,:] over rows with
+ * row2site[i]==s, accumulated in fp64 (order independent), rounded once.
+ * acc64 is scratch of n_cap*nf doubles. */
+int urn_input_features(const float *feats, const int32_t *row2site, int64_t n, int nf,
+                       const int32_t *n_active, int64_t n_cap, double *acc64, float *site_feats,
+                       void *stream);
+
+/* scn.SubmanifoldConvolution rulebook (reference uresnet_sparse.py:21,22): 27-offset
+ * neighbour table nbr[27][ld], o = ((dx+1)*3+(dy+1))*3+(dz+1), neighbour = site+(dx,dy,dz).
+ * n_rules (device int32, may be NULL) receives the number of valid entries. */
+int urn_rulebook_subm(const int32_t *site_coords, const int32_t *n_dev, int64_t n_cap, int spatial,
+                      const void *hash, int64_t hcap, int32_t *nbr, int64_t ld, int32_t *n_rules,
+                      void *stream);
+
+/* scn.Convolution(d, a, b, 2, 2, False) site creation inside scn.UNet (reference
+ * uresnet_sparse.py:22): coarse = fine>>1 in first-touch order.  Outputs
+ * coarse_coords[n_cap][4], parent[n_cap], off[n_cap] (0..7), n_coarse (device), and the
+ * coarse level's hash (cleared by the caller beforehand). */
+int urn_level_down(const int32_t *fine_coords, const int32_t *n_fine, int64_t n_cap, void *hash,
+                   int64_t hcap, void *scratch, int64_t scratch_bytes, int32_t *coarse_coords,
+                   int32_t *parent, int32_t *off, int32_t *n_coarse, void *stream);
+
+/* Gather tables of the strided pair: chd[8][ld_c] (coarse j <- fine child at offset o) and
+ * up[8][ld_f] (fine i <- parent[i] at o == off[i]).  Both must be pre-filled with -1
+ * by the caller (urn_fill_i32). */
+int urn_down_tables(const int32_t *parent, const int32_t *off, const int32_t *n_fine, int64_t n_cap,
+                    int32_t *chd, int64_t ld_c, int32_t *up, int64_t ld_f, void *stream);
+
+int urn_fill_i32(int32_t *p, int64_t n, int32_t v, void *stream);
+
+/* -------------------------------------------------------------------- float phase
+ * Gather convolution, the one arithmetic kernel behind SubmanifoldConvolution,
+ * Convolution(k2,s2) and Deconvolution(k2,s2) forward and input-gradient:
+ *     y[j,:] = sum_{o<K} x[tbl[t(o)*ld + j], :] @ W[o]   (+ res[j,:] if res)
+ * with t(o) = flip ? K-1-o : o.  `wt` is W pre-transposed to (K, cout, cin).
+ * cin, cout multiples of 16 use the MFMA kernel (v_mfma_f32_16x16x4_f32); other
+ * widths (the 1-channel stem) use a VALU kernel.  y may not alias x. */
+int urn_gconv_fwd(const float *x, const float *wt, const int32_t *tbl, int64_t ld, int K, int flip,
+                  int64_t n_out, int cin, int cout, const float *res, float *y, void *stream);
+
+/* Weight gradient of the same op: dw[o] (+)= sum_j x[tbl[o*ld+j],:]^T (x) dy[j,:],
+ * dw is (K, cin, cout) and is ACCUMULATED into (fp32 atomics; caller zeroes). */
+int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *tbl, int64_t ld, int K,
+                     int64_t n_out, int cin, int cout, float *dw, void *stream);
+
+/* (K, a, b) -> (K, b, a) */
+int urn_transpose_w(const float *w, int K, int a, int b, float *wt, void *stream);
+
+/* scn.BatchNormReLU / BatchNormLeakyReLU(leak 0) over the (n, c) row matrix, batch
+ * statistics (biased variance), fp64 accumulation.  scratch: urn_bn_scratch_bytes(c).
+ * mean/invstd (c) are outputs of fwd and inputs of bwd.  relu: 0/1.
+ * running_mean/var may be NULL; otherwise updated with `momentum` (new = m*old + (1-m)*batch). */
+int64_t urn_bn_scratch_bytes(int c);
+int urn_bn_relu_fwd(const float *x, int64_t n, int c, const float *gamma, const float *beta,
+                    double eps, int relu, float *y, float *mean, float *invstd,
+                    float *running_mean, float *running_var, double momentum, void *scratch,
+                    void *stream);
+/* Affine+ReLU with given statistics (eval mode: running stats). */
+int urn_bn_relu_apply(const float *x, int64_t n, int c, const float *gamma, const float *beta,
+                      const float *mean, const float *invstd, int relu, float *y, void *stream);
+int urn_bn_relu_bwd(const float *x, const float *y, const float *dy, int64_t n, int c,
+                    const float *gamma, const float *mean, const float *invstd, int relu,
+                    float *dx, float *dgamma, float *dbeta, void *scratch, void *stream);
+
+/* scn.OutputLayer (reference uresnet_sparse.py:24): y[i,:] = x[idx[i],:]; and its
+ * backward dx[idx[i],:] += dy[i,:] (fp32 atomics; caller zeroes dx). */
+int urn_rows_gather(const float *x, const int32_t *idx, int64_t n, int c, float *y, void *stream);
+int urn_rows_scatter_add(const float *dy, const int32_t *idx, int64_t n, int c, float *dx,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URESNET_HIP_H */

@@ -127,8 +127,8 @@ int64_t orc_sites_build(const int32_t *coords, int64_t N, const float *feats, in
             for (int f = 0; f < nf; ++f) {
                 double *a = &acc[(int64_t)s * nf + f];
                 if (mode == 3 || mode == 4) {
-                    /* fp32 running sum in row order, as a sequential host loop would */
-                    *a = (double)(float)((float)*a + feats[i * nf + f]);
+                    /* fp64 sum, rounded once at the end: independent of row order */
+                    *a += (double)feats[i * nf + f];
                 } else if (mode == 1) {
                     *a = feats[i * nf + f];
                 } /* mode 2: keep first */

@@ -1,0 +1,227 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+Integer results are compared bit-exact; fp32 results within 1e-5 relative (norm-wise),
+the tolerance BASELINE.json's north_star states."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_oracle as orc
+from uresnet_pytorch_amd.iotools.synthetic import generate_event, make_sparse_blob
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def cloud(seed, S, n, nbatch, dup):
+    rng = np.random.default_rng(seed)
+    cs = []
+    for b in range(nbatch):
+        c, _, _ = generate_event(seed * 10 + b, S, n)
+        cs.append(np.concatenate([c, np.full((len(c), 1), b, np.int32)], 1))
+    c = np.concatenate(cs, 0)
+    if dup:
+        c = np.concatenate([c, c[rng.integers(0, len(c), dup)]], 0)
+        c = c[rng.permutation(len(c))]
+    f = rng.normal(size=(len(c), 1)).astype(np.float32)
+    return np.ascontiguousarray(c, np.int32), f
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from uresnet_pytorch_amd import lib
+    lib.load()
+    return torch.device('cuda:0')
+
+
+def check_geometry(c, f, S, L, dev):
+    from uresnet_pytorch_amd import sparse_ops as so
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, L)
+    ref = orc.Geometry(c, f, S, L)
+    assert geo.n == ref.n
+    assert np.array_equal(geo.row2site[:len(c)].cpu().numpy(), ref.row2site)
+    for l in range(L):
+        assert np.array_equal(geo.export_coords(l), ref.coords[l]), 'site coords level %d' % l
+        assert np.array_equal(geo.export_nbr(l), ref.nbr[l]), 'subm table level %d' % l
+        assert geo.rules[l] == ref.R[l]
+        # canonical (offset, in, out) triples, sorted
+        assert np.array_equal(orc.canonical_triples(geo.export_nbr(l)), orc.canonical_triples(ref.nbr[l]))
+        if l + 1 < L:
+            n, nc = geo.n[l], geo.n[l + 1]
+            assert np.array_equal(geo.parent[l][:n].cpu().numpy(), ref.parent[l])
+            assert np.array_equal(geo.off[l][:n].cpu().numpy(), ref.off[l])
+            assert np.array_equal(geo.chd[l][:, :nc].cpu().numpy(), ref.chd[l])
+            assert np.array_equal(geo.up[l][:, :n].cpu().numpy(), ref.up[l])
+    sf = so.input_features(geo, torch.from_numpy(f).to(dev)).cpu().numpy()
+    assert np.array_equal(sf, ref.feats)       # fp64 accumulation, one rounding: bit-exact
+    return geo, ref
+
+
+@pytest.mark.parametrize('seed,S,n,nb,dup,L', [(1, 24, 400, 2, 37, 3), (2, 64, 3000, 3, 0, 4), (3, 16, 50, 1, 200, 2)])
+def test_integer_phase_bit_exact(dev, seed, S, n, nb, dup, L):
+    c, f = cloud(seed, S, n, nb, dup)
+    check_geometry(c, f, S, L, dev)
+
+
+def test_integer_phase_edges(dev):
+    # volume border (no wrap-around), a single site, many duplicates of one site
+    S = 8
+    c = np.array([[0, 0, 0, 0], [7, 7, 7, 0], [0, 0, 1, 0], [7, 7, 6, 1], [7, 7, 6, 1], [7, 7, 6, 1]], np.int32)
+    f = np.arange(len(c), dtype=np.float32)[:, None]
+    check_geometry(c, f, S, 3, dev)
+    c1 = np.array([[3, 4, 5, 0]], np.int32)
+    check_geometry(c1, np.ones((1, 1), np.float32), S, 2, dev)
+
+
+def test_integer_phase_full_size(dev):
+    """BASELINE cfg3 size: 512^3, 50k active voxels, 5 levels -- bit-exact against the oracle."""
+    blob = make_sparse_blob([0], 512, 50000)
+    c = blob['data'][:, :4].astype(np.int32)
+    f = blob['data'][:, 4:5].copy()
+    geo, ref = check_geometry(c, f, 512, 5, dev)
+    assert geo.n[0] == 50000
+
+
+CONV_SHAPES = [(1, 16), (16, 16), (16, 32), (32, 48), (80, 80), (128, 64), (96, 48)]
+
+
+@pytest.mark.parametrize('cin,cout', CONV_SHAPES)
+def test_subm_conv_fwd_bwd(dev, cin, cout):
+    from uresnet_pytorch_amd import sparse_ops as so
+    S = 32
+    c, f = cloud(7, S, 1500, 2, 0)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
+    ref = orc.Geometry(c, f, S, 1)
+    n = ref.n[0]
+    rng = np.random.default_rng(cin * 100 + cout)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    res = rng.normal(size=(n, cout)).astype(np.float32)
+    dy = rng.normal(size=(n, cout)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    Wt = torch.from_numpy(W).to(dev).requires_grad_(True)
+    rt = torch.from_numpy(res).to(dev).requires_grad_(True)
+    y = so.GConvFunction.apply(xt, Wt, rt, geo.nbr[0], geo.nbr[0], 1, geo.ld, n, n)
+    y.backward(torch.from_numpy(dy).to(dev))
+    y_ref = orc.conv_fwd(x, W, ref.nbr[0]) + res
+    dx_ref, dW_ref = orc.conv_bwd(x, W, ref.nbr[0], dy, ref.nbr_inv[0])
+    assert rel(y.detach().cpu().numpy(), y_ref) < TOL
+    assert rel(xt.grad.cpu().numpy(), dx_ref) < TOL
+    assert rel(Wt.grad.cpu().numpy(), dW_ref) < TOL
+    assert np.array_equal(rt.grad.cpu().numpy(), dy)
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 32), (64, 80), (48, 32)])
+def test_strided_conv_deconv_fwd_bwd(dev, cin, cout):
+    from uresnet_pytorch_amd import sparse_ops as so
+    S = 32
+    c, f = cloud(8, S, 1500, 2, 0)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 2)
+    ref = orc.Geometry(c, f, S, 2)
+    nf, nc = ref.n
+    rng = np.random.default_rng(cin + cout)
+    # down: fine -> coarse
+    x = rng.normal(size=(nf, cin)).astype(np.float32)
+    W = (rng.normal(size=(8, cin, cout)) / np.sqrt(8 * cin)).astype(np.float32)
+    dy = rng.normal(size=(nc, cout)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    Wt = torch.from_numpy(W).to(dev).requires_grad_(True)
+    y = so.GConvFunction.apply(xt, Wt, None, geo.chd[0], geo.up[0], 0, geo.ld, nc, nf)
+    y.backward(torch.from_numpy(dy).to(dev))
+    dx_ref, dW_ref = orc.conv_bwd(x, W, ref.chd[0], dy, ref.chd_inv[0])
+    assert rel(y.detach().cpu().numpy(), orc.conv_fwd(x, W, ref.chd[0])) < TOL
+    assert rel(xt.grad.cpu().numpy(), dx_ref) < TOL and rel(Wt.grad.cpu().numpy(), dW_ref) < TOL
+    # up: coarse -> fine
+    z = rng.normal(size=(nc, cout)).astype(np.float32)
+    Wu = (rng.normal(size=(8, cout, cin)) / np.sqrt(8 * cout)).astype(np.float32)
+    du = rng.normal(size=(nf, cin)).astype(np.float32)
+    zt = torch.from_numpy(z).to(dev).requires_grad_(True)
+    Wut = torch.from_numpy(Wu).to(dev).requires_grad_(True)
+    u = so.GConvFunction.apply(zt, Wut, None, geo.up[0], geo.chd[0], 0, geo.ld, nf, nc)
+    u.backward(torch.from_numpy(du).to(dev))
+    dz_ref, dWu_ref = orc.conv_bwd(z, Wu, ref.up[0], du, ref.up_inv[0])
+    assert rel(u.detach().cpu().numpy(), orc.conv_fwd(z, Wu, ref.up[0])) < TOL
+    assert rel(zt.grad.cpu().numpy(), dz_ref) < TOL and rel(Wut.grad.cpu().numpy(), dWu_ref) < TOL
+
+
+@pytest.mark.parametrize('n,c', [(1000, 16), (4097, 48), (300, 160), (1, 16), (50000, 80)])
+def test_bn_relu_fwd_bwd(dev, n, c):
+    from uresnet_pytorch_amd import sparse_ops as so
+    rng = np.random.default_rng(n + c)
+    x = (rng.normal(size=(n, c)) * 2 + 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.normal(size=c)).astype(np.float32)
+    b = (0.1 * rng.normal(size=c)).astype(np.float32)
+    dy = rng.normal(size=(n, c)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    gt = torch.from_numpy(g).to(dev).requires_grad_(True)
+    bt = torch.from_numpy(b).to(dev).requires_grad_(True)
+    rm = torch.zeros(c, device=dev); rv = torch.ones(c, device=dev)
+    y = so.BNReLUFunction.apply(xt, gt, bt, rm, rv, orc.BN_EPS, 0.9, True, True)
+    y.backward(torch.from_numpy(dy).to(dev))
+    y_ref, mean, invstd = orc.bn_relu_fwd(x, g, b, True)
+    dx_ref, dg_ref, db_ref = orc.bn_relu_bwd(x, y_ref, dy, g, mean, invstd, True)
+    assert rel(y.detach().cpu().numpy(), y_ref) < TOL
+    if n > 1:
+        assert rel(xt.grad.cpu().numpy(), dx_ref) < 5 * TOL
+        assert rel(gt.grad.cpu().numpy(), dg_ref) < 5 * TOL
+    assert rel(bt.grad.cpu().numpy(), db_ref) < TOL
+    assert rel(rm.cpu().numpy(), 0.1 * mean) < 1e-4
+
+
+def make_model(flags, P, dev):
+    from uresnet_pytorch_amd.models import SparseUResNet
+    m = SparseUResNet(flags)
+    sd = m.state_dict()
+    for k, v in P.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v)
+    m.load_state_dict(sd)
+    return m.to(dev).train()
+
+
+def run_network_parity(dev, S, m, L, nc, pc, lab, tol_fwd, tol_grad):
+    from uresnet_pytorch_amd.models import SparseSegmentationLoss
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=L, SPATIAL_SIZE=S, NUM_CLASS=nc)
+    P = orc.init_params(m, L, nc, seed=1)
+    net = make_model(flags, P, dev)
+    data = torch.from_numpy(pc).to(dev)
+    label = torch.from_numpy(lab).to(dev)
+    out = net(data)
+    loss, acc = SparseSegmentationLoss(flags)(out, [data], [label], None)
+    loss.backward()
+    ref = orc.SparseUResNetOracle(P, m, L, nc, S)
+    logits_ref = ref.forward(pc)
+    loss_ref, acc_ref, dl = orc.segmentation_loss(logits_ref, pc, lab)
+    G, _ = ref.backward(dl)
+    e_fwd = rel(out[0].detach().cpu().numpy(), logits_ref)
+    assert e_fwd < tol_fwd, e_fwd
+    assert abs(loss.item() - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    assert abs(acc - acc_ref) < 1e-6
+    worst = 0.0
+    for k, p in net.named_parameters():
+        e = rel(p.grad.cpu().numpy(), G[k])
+        worst = max(worst, e)
+        assert e < tol_grad, (k, e)
+    return e_fwd, worst
+
+
+def test_network_small(dev):
+    S, m, L, nc = 32, 16, 3, 5
+    c, f = cloud(6, S, 800, 2, 11)
+    pc = np.concatenate([c.astype(np.float32), f], 1)
+    lab = np.random.default_rng(3).integers(0, nc, size=(len(pc), 1)).astype(np.float32)
+    run_network_parity(dev, S, m, L, nc, pc, lab, TOL, 5 * TOL)
+
+
+def test_network_cfg3_full_size(dev):
+    """BASELINE cfg3: -dd 3 -ss 512 ~50k voxels -nc 5 -uf 16 -uns 5, fp32, fwd+bwd vs the oracle."""
+    blob = make_sparse_blob([0], 512, 50000)
+    e_fwd, e_grad = run_network_parity(dev, 512, 16, 5, 5, blob['data'], blob['label'], TOL, 5 * TOL)
+    print('cfg3 parity: logits rel err %.2e, worst grad rel err %.2e' % (e_fwd, e_grad))

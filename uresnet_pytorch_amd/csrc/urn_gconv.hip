@@ -1,0 +1,340 @@
+// Gather convolution on gfx950: the arithmetic behind scn.SubmanifoldConvolution,
+// scn.Convolution(k2,s2) and scn.Deconvolution(k2,s2) forward, input-gradient and
+// weight-gradient (reference call sites uresnet/models/uresnet_sparse.py:21-22).
+//
+//   y[j,:] = sum_{o<K} x[tbl[t(o)*ld + j], :] @ W[o]
+//
+// Forward / input-gradient kernel (output stationary, no atomics, deterministic):
+//   one wave owns MB*16 output rows x NB*16 output columns; for each filter offset
+//   it ballots whether any of its rows has an active neighbour and skips the offset
+//   otherwise; A fragments are gathered straight from HBM/L2 in MFMA operand layout
+//   (one 16-byte load per lane = 4 k-values of one gathered row), B fragments come
+//   from the pre-transposed weights (K, cout, cin) which stay L2-resident;
+//   v_mfma_f32_16x16x4_f32 accumulates in fp32 (exact f32 fma chain).
+// Weight-gradient kernel: rows are the reduction dimension, so the valid (in,out)
+//   pairs of an offset are compacted with wave64 ballot/popcount prefix sums, staged
+//   through LDS in batches of 32 pairs and contracted with the same MFMA.
+#include "urn_common.h"
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------ forward / dX --
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void k_gconv_fwd(const float *__restrict__ x, const float *__restrict__ wt,
+                                                   const int *__restrict__ tbl, long ld, int K, int flip,
+                                                   long n_out, int cin, int cout,
+                                                   const float *__restrict__ res, float *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const long row_base = ((long)blockIdx.x * 4 + wave) * (MB * 16);
+    if (row_base >= n_out) return;  // wave-uniform
+    const int col_base = blockIdx.y * (NB * 16);
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int o = 0; o < K; ++o) {
+        const int to = flip ? (K - 1 - o) : o;
+        int idx[MB];
+        bool act[MB];
+        bool any = false;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            long row = row_base + mb * 16 + r;
+            idx[mb] = (row < n_out) ? tbl[(long)to * ld + row] : -1;
+            act[mb] = __ballot(idx[mb] >= 0) != 0ull;
+            any |= act[mb];
+        }
+        if (!any) continue;  // wave-uniform
+        const float *wo = wt + (long)o * cout * cin + (long)(col_base + r) * cin + 4 * q;
+        for (int k0 = 0; k0 < cin; k0 += 16) {
+            f32x4 a[MB], b[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                a[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (idx[mb] >= 0) a[mb] = *(const f32x4 *)(x + (long)idx[mb] * cin + k0 + 4 * q);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4 *)(wo + (long)nb * 16 * cin + k0);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                if (!act[mb]) continue;  // wave-uniform
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = MFMA16(a[mb][t], b[nb][t], acc[mb][nb]);
+            }
+        }
+    }
+    // C layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long row = row_base + mb * 16 + q * 4 + i;
+            if (row >= n_out) continue;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                long off = row * cout + col_base + nb * 16 + r;
+                float v = acc[mb][nb][i];
+                if (res) v += res[off];
+                y[off] = v;
+            }
+        }
+}
+
+// VALU fallback for widths that are not multiples of 16 (the 1-channel stem).
+__global__ void k_gconv_small(const float *__restrict__ x, const float *__restrict__ wt,
+                              const int *__restrict__ tbl, long ld, int K, int flip, long n_out, int cin,
+                              int cout, const float *__restrict__ res, float *__restrict__ y)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_out * cout) return;
+    long j = t / cout;
+    int c = (int)(t - j * cout);
+    float acc = 0.f;
+    for (int o = 0; o < K; ++o) {
+        int to = flip ? (K - 1 - o) : o;
+        int i = tbl[(long)to * ld + j];
+        if (i < 0) continue;
+        const float *xi = x + (long)i * cin;
+        const float *w = wt + ((long)o * cout + c) * cin;
+        for (int a = 0; a < cin; ++a) acc = fmaf(xi[a], w[a], acc);
+    }
+    if (res) acc += res[t];
+    y[t] = acc;
+}
+
+template <int MB, int NB>
+static void launch_fwd(const float *x, const float *wt, const int *tbl, long ld, int K, int flip, long n_out,
+                       int cin, int cout, const float *res, float *y, hipStream_t st)
+{
+    dim3 grid(urn_cdiv(n_out, 4 * MB * 16), cout / (NB * 16));
+    hipLaunchKernelGGL((k_gconv_fwd<MB, NB>), grid, dim3(256), 0, st, x, wt, tbl, ld, K, flip, n_out, cin, cout,
+                       res, y);
+}
+
+extern "C" int urn_gconv_fwd(const float *x, const float *wt, const int32_t *tbl, int64_t ld, int K, int flip,
+                             int64_t n_out, int cin, int cout, const float *res, float *y, void *stream)
+{
+    if (n_out <= 0) return URN_OK;
+    URN_CHECK_ARG(x && wt && tbl && y, "null pointer");
+    URN_CHECK_ARG(K > 0 && cin > 0 && cout > 0 && ld >= n_out, "bad shape");
+    URN_CHECK_ARG((const void *)x != (const void *)y, "y aliases x");
+    hipStream_t st = (hipStream_t)stream;
+    if ((cin % 16) || (cout % 16)) {
+        hipLaunchKernelGGL(k_gconv_small, dim3(urn_cdiv(n_out * cout, 256)), dim3(256), 0, st, x, wt, tbl, (long)ld,
+                           K, flip, (long)n_out, cin, cout, res, y);
+        URN_LAUNCH_CHECK();
+        return URN_OK;
+    }
+    const int nblk = cout / 16;
+    // columns per wave: the largest divisor of cout/16 that is <= 5
+    int nb = 1;
+    for (int d = 5; d >= 1; --d)
+        if (nblk % d == 0) { nb = d; break; }
+    // rows per wave: 32 when that still fills the chip, else 16
+    const bool big = (n_out / 128) * (nblk / nb) >= 512;
+#define URN_FWD(MBv, NBv) launch_fwd<MBv, NBv>(x, wt, tbl, ld, K, flip, n_out, cin, cout, res, y, st)
+    switch (nb) {
+    case 1: big ? URN_FWD(2, 1) : URN_FWD(1, 1); break;
+    case 2: big ? URN_FWD(2, 2) : URN_FWD(1, 2); break;
+    case 3: big ? URN_FWD(2, 3) : URN_FWD(1, 3); break;
+    case 4: big ? URN_FWD(2, 4) : URN_FWD(1, 4); break;
+    default: big ? URN_FWD(2, 5) : URN_FWD(1, 5); break;
+    }
+#undef URN_FWD
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// ---------------------------------------------------------------- weight gradient --
+// grid (row chunks, K, output tiles); block 256 = 4 waves.
+// Output tile: up to 4 ci-blocks x 5 co-blocks of 16x16, block b -> wave b%4, slot b/4.
+#define DW_KT 32      // pairs per MFMA batch
+#define DW_MAXI 4     // ci blocks per tile  (64 channels)
+#define DW_MAXN 5     // co blocks per tile  (80 channels)
+#define DW_SLOTS 5    // ceil(4*5/4)
+#define DW_LIST 1024
+
+__global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, const float *__restrict__ dy,
+                                                  const int *__restrict__ tbl, long ld, long n_out, int cin,
+                                                  int cout, long chunk, int n_ci_tiles,
+                                                  float *__restrict__ dw)
+{
+    __shared__ int s_in[DW_LIST], s_out[DW_LIST];
+    __shared__ int s_wcnt[4];
+    __shared__ float s_a[DW_KT][DW_MAXI * 16 + 16];
+    __shared__ float s_b[DW_KT][DW_MAXN * 16 + 32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int o = blockIdx.y;
+    const int ci_tile = blockIdx.z % n_ci_tiles, co_tile = blockIdx.z / n_ci_tiles;
+    const int ci0 = ci_tile * DW_MAXI * 16, co0 = co_tile * DW_MAXN * 16;
+    const int ci_w = min(DW_MAXI * 16, cin - ci0), co_w = min(DW_MAXN * 16, cout - co0);
+    const int mi_n = ci_w / 16, ni_n = co_w / 16, nblk = mi_n * ni_n;
+
+    f32x4 acc[DW_SLOTS];
+#pragma unroll
+    for (int s = 0; s < DW_SLOTS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long row_begin = (long)blockIdx.x * chunk;
+    const long row_end = min(n_out, row_begin + chunk);
+    int cnt = 0;  // pairs currently in the list (block-uniform)
+
+    for (long row0 = row_begin; row0 < row_end || cnt > 0; row0 += 256) {
+        const bool last = row0 >= row_end;
+        if (!last) {
+            // compact the valid (in,out) pairs of 256 candidate rows, order preserved
+            long row = row0 + tid;
+            int idx = (row < row_end) ? tbl[(long)o * ld + row] : -1;
+            unsigned long long bal = __ballot(idx >= 0);
+            if (lane == 0) s_wcnt[wave] = __popcll(bal);
+            __syncthreads();
+            int base = cnt, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                int v = s_wcnt[w];
+                if (w < wave) base += v;
+                tot += v;
+            }
+            if (idx >= 0) {
+                int p = base + __popcll(bal & ((1ull << lane) - 1ull));
+                s_in[p] = idx;
+                s_out[p] = (int)row;
+            }
+            cnt += tot;
+            __syncthreads();
+        }
+        // consume full batches (and the final partial one)
+        int done = 0;
+        while (cnt - done >= DW_KT || (last && cnt - done > 0)) {
+            const int nb = min(DW_KT, cnt - done);
+            // stage gathered x rows and dy rows (this tile's columns), zero-fill the tail
+            for (int e = tid; e < DW_KT * (ci_w / 4); e += 256) {
+                int rr = e / (ci_w / 4), c4 = e - rr * (ci_w / 4);
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rr < nb) v = *(const f32x4 *)(x + (long)s_in[done + rr] * cin + ci0 + 4 * c4);
+                *(f32x4 *)&s_a[rr][4 * c4] = v;
+            }
+            for (int e = tid; e < DW_KT * (co_w / 4); e += 256) {
+                int rr = e / (co_w / 4), c4 = e - rr * (co_w / 4);
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rr < nb) v = *(const f32x4 *)(dy + (long)s_out[done + rr] * cout + co0 + 4 * c4);
+                *(f32x4 *)&s_b[rr][4 * c4] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < DW_SLOTS; ++s) {
+                int b = wave + 4 * s;
+                if (b < nblk) {  // wave-uniform
+                    int mi = b / ni_n, ni = b - mi * ni_n;
+#pragma unroll
+                    for (int ks = 0; ks < DW_KT / 4; ++ks) {
+                        float av = s_a[4 * ks + q][mi * 16 + m];
+                        float bv = s_b[4 * ks + q][ni * 16 + m];
+                        acc[s] = MFMA16(av, bv, acc[s]);
+                    }
+                }
+            }
+            __syncthreads();
+            done += nb;
+        }
+        // move the remainder (< DW_KT pairs) to the front of the list
+        int rem = cnt - done;
+        int vi = 0, vo = 0;
+        if (tid < rem) { vi = s_in[done + tid]; vo = s_out[done + tid]; }
+        __syncthreads();
+        if (tid < rem) { s_in[tid] = vi; s_out[tid] = vo; }
+        cnt = rem;
+        __syncthreads();
+        if (last) break;
+    }
+    // accumulate this block's partial into dw[o][ci][co]; C layout: col = lane&15, row = q*4+i
+#pragma unroll
+    for (int s = 0; s < DW_SLOTS; ++s) {
+        int b = wave + 4 * s;
+        if (b < nblk) {
+            int mi = b / ni_n, ni = b - mi * ni_n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int ci = ci0 + mi * 16 + q * 4 + i, co = co0 + ni * 16 + m;
+                atomicAdd(&dw[((long)o * cin + ci) * cout + co], acc[s][i]);
+            }
+        }
+    }
+}
+
+__global__ void k_gconv_dw_small(const float *__restrict__ x, const float *__restrict__ dy,
+                                 const int *__restrict__ tbl, long ld, long n_out, int cin, int cout,
+                                 long chunk, float *__restrict__ dw)
+{
+    // grid (chunks, K); thread e -> (ci, co) pairs, strided
+    const int o = blockIdx.y;
+    const long row_begin = (long)blockIdx.x * chunk, row_end = min(n_out, row_begin + chunk);
+    for (int e = threadIdx.x; e < cin * cout; e += blockDim.x) {
+        int ci = e / cout, co = e - ci * cout;
+        float acc = 0.f;
+        for (long j = row_begin; j < row_end; ++j) {
+            int i = tbl[(long)o * ld + j];
+            if (i >= 0) acc = fmaf(x[(long)i * cin + ci], dy[j * cout + co], acc);
+        }
+        atomicAdd(&dw[((long)o * cin + ci) * cout + co], acc);
+    }
+}
+
+extern "C" int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *tbl, int64_t ld, int K,
+                                int64_t n_out, int cin, int cout, float *dw, void *stream)
+{
+    if (n_out <= 0) return URN_OK;
+    URN_CHECK_ARG(x && dy && tbl && dw, "null pointer");
+    URN_CHECK_ARG(K > 0 && cin > 0 && cout > 0 && ld >= n_out, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if ((cin % 16) || (cout % 16)) {
+        int chunks = (int)((n_out + 1023) / 1024);
+        if (chunks > 128) chunks = 128;
+        long chunk = (n_out + chunks - 1) / chunks;
+        hipLaunchKernelGGL(k_gconv_dw_small, dim3(chunks, K), dim3(64), 0, st, x, dy, tbl, (long)ld, (long)n_out,
+                           cin, cout, chunk, dw);
+        URN_LAUNCH_CHECK();
+        return URN_OK;
+    }
+    const int n_ci_tiles = urn_cdiv(cin, DW_MAXI * 16), n_co_tiles = urn_cdiv(cout, DW_MAXN * 16);
+    // aim for ~1024 blocks, chunks of at least 512 rows (multiple of 256)
+    int chunks = 1024 / (K * n_ci_tiles * n_co_tiles);
+    if (chunks < 1) chunks = 1;
+    long chunk = (n_out + chunks - 1) / chunks;
+    if (chunk < 512) chunk = 512;
+    chunk = ((chunk + 255) / 256) * 256;
+    chunks = (int)((n_out + chunk - 1) / chunk);
+    hipLaunchKernelGGL(k_gconv_dw, dim3(chunks, K, n_ci_tiles * n_co_tiles), dim3(256), 0, st, x, dy, tbl, (long)ld,
+                       (long)n_out, cin, cout, chunk, n_ci_tiles, dw);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// ----------------------------------------------------------------- weight transpose --
+__global__ void k_transpose_w(const float *__restrict__ w, int a, int b, float *__restrict__ wt)
+{
+    // grid.y = K; wt[o][j][i] = w[o][i][j]
+    const long base = (long)blockIdx.y * a * b;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a * b; e += gridDim.x * blockDim.x) {
+        int j = e / a, i = e - j * a;
+        wt[base + e] = w[base + (long)i * b + j];
+    }
+}
+
+extern "C" int urn_transpose_w(const float *w, int K, int a, int b, float *wt, void *stream)
+{
+    URN_CHECK_ARG(w && wt && K > 0 && a > 0 && b > 0, "bad argument");
+    int gx = urn_cdiv((int64_t)a * b, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_transpose_w, dim3(gx, K), dim3(256), 0, (hipStream_t)stream, w, a, b, wt);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}

@@ -1,0 +1,387 @@
+// Integer phase: coordinate hash, first-occurrence site numbering, submanifold
+// rulebook, strided-level tables.  HBM-bound integer work: coalesced reads of the
+// COO coordinate list, 64-bit CAS linear-probing hash in HBM (L2-resident at these
+// sizes), wave64 ballot + popcount prefix sums for the order-preserving compaction.
+//
+// Replaces the host-side hash-map work behind scn.InputLayer / scn.SubmanifoldConvolution /
+// scn.Convolution at reference uresnet/models/uresnet_sparse.py:20-22.
+#include "urn_common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void urn_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *urn_last_error(void) { return g_err; }
+extern "C" int urn_version(void) { return 100; }
+
+#define UB 256  // threads per block in the unique pipeline
+
+struct HashView {
+    unsigned long long *keys;
+    int *first;  // smallest row index that inserted the key
+    int *site;   // site number of the key
+    unsigned long long mask;
+};
+
+static inline HashView hash_view(void *hash, int64_t hcap)
+{
+    HashView h;
+    h.keys = (unsigned long long *)hash;
+    h.first = (int *)((char *)hash + 8 * hcap);
+    h.site = h.first + hcap;
+    h.mask = (unsigned long long)hcap - 1;
+    return h;
+}
+
+extern "C" int64_t urn_hash_capacity(int64_t n)
+{
+    int64_t cap = 1024;
+    while (cap < 2 * n + 2) cap <<= 1;
+    return cap;
+}
+extern "C" int64_t urn_hash_bytes(int64_t hcap) { return hcap * 16; }
+
+static inline int64_t n_blocks(int64_t n) { return (n + UB - 1) / UB; }
+
+extern "C" int64_t urn_unique_scratch_bytes(int64_t n)
+{
+    // rowslot[n] | blocksum[nblk + 1], 256-byte aligned pieces
+    int64_t a = ((4 * n + 255) / 256) * 256;
+    int64_t b = ((4 * (n_blocks(n) + 1) + 255) / 256) * 256;
+    return a + b + 256;
+}
+
+extern "C" int urn_hash_clear(void *hash, int64_t bytes, void *stream)
+{
+    URN_CHECK_ARG(hash && bytes >= 0, "null hash");
+    if (hipMemsetAsync(hash, 0x7F, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
+        urn_set_error("urn_hash_clear: hipMemsetAsync failed");
+        return URN_EHIP;
+    }
+    return URN_OK;
+}
+
+__global__ void k_fill_i32(int *p, long n, int v)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+extern "C" int urn_fill_i32(int32_t *p, int64_t n, int32_t v, void *stream)
+{
+    if (n <= 0) return URN_OK;
+    URN_CHECK_ARG(p, "null pointer");
+    int grid = urn_cdiv(n, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_fill_i32, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (long)n, v);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// ---- unique-by-first-occurrence pipeline --------------------------------------------
+// U1: insert keys, remember the smallest inserting row per slot.
+__global__ void k_insert(const int *__restrict__ coords, const int *n_dev, long n_cap, int shift,
+                         HashView h, int *__restrict__ rowslot)
+{
+    long n = n_dev ? (long)*n_dev : n_cap;
+    long i = (long)blockIdx.x * UB + threadIdx.x;
+    if (i >= n) return;
+    int4 c = ((const int4 *)coords)[i];
+    unsigned long long key = urn_key(c.x >> shift, c.y >> shift, c.z >> shift, c.w);
+    unsigned long long s = urn_mix(key) & h.mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&h.keys[s], URN_EMPTY_KEY, key);
+        if (prev == URN_EMPTY_KEY || prev == key) break;
+        s = (s + 1) & h.mask;
+    }
+    atomicMin(&h.first[s], (int)i);
+    rowslot[i] = (int)s;
+}
+
+// block-wide exclusive prefix of a 0/1 flag; returns this thread's prefix, total in *tot
+__device__ __forceinline__ int block_prefix(bool flag, int *tot)
+{
+    __shared__ int s_w[UB / 64 + 1];
+    unsigned long long b = __ballot(flag);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int pre = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[w] = __popcll(b);
+    __syncthreads();
+    int base = 0, t = 0;
+#pragma unroll
+    for (int k = 0; k < UB / 64; ++k) {
+        int v = s_w[k];
+        if (k < w) base += v;
+        t += v;
+    }
+    *tot = t;
+    __syncthreads();
+    return base + pre;
+}
+
+// U2: per-block count of first-occurrence rows
+__global__ void k_flag_count(const int *n_dev, long n_cap, HashView h, const int *__restrict__ rowslot,
+                             int *__restrict__ blocksum)
+{
+    long n = n_dev ? (long)*n_dev : n_cap;
+    long i = (long)blockIdx.x * UB + threadIdx.x;
+    bool f = (i < n) && (h.first[rowslot[i]] == (int)i);
+    int tot;
+    block_prefix(f, &tot);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+// U3: exclusive scan of the block sums by one 1024-thread block
+__global__ void k_scan_blocks(int *blocksum, int nblk, int *n_unique)
+{
+    __shared__ int s[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        int i = b0 + threadIdx.x;
+        int v = i < nblk ? blocksum[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            int t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int incl = s[threadIdx.x];
+        int c = carry;
+        if (i < nblk) blocksum[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_unique = carry;
+}
+
+// U4: number the first-occurrence rows in row order, write site coords, publish slot->site
+__global__ void k_assign(const int *__restrict__ coords, const int *n_dev, long n_cap, int shift,
+                         HashView h, const int *__restrict__ rowslot,
+                         const int *__restrict__ blocksum, int *__restrict__ site_coords)
+{
+    long n = n_dev ? (long)*n_dev : n_cap;
+    long i = (long)blockIdx.x * UB + threadIdx.x;
+    int slot = (i < n) ? rowslot[i] : 0;
+    bool f = (i < n) && (h.first[slot] == (int)i);
+    int tot;
+    int pre = block_prefix(f, &tot);
+    if (f) {
+        int s = blocksum[blockIdx.x] + pre;
+        int4 c = ((const int4 *)coords)[i];
+        c.x >>= shift; c.y >>= shift; c.z >>= shift;
+        ((int4 *)site_coords)[s] = c;
+        h.site[slot] = s;
+    }
+}
+
+// U5a: input rows -> site
+__global__ void k_row2site(const int *n_dev, long n_cap, HashView h, const int *__restrict__ rowslot,
+                           int *__restrict__ row2site)
+{
+    long n = n_dev ? (long)*n_dev : n_cap;
+    long i = (long)blockIdx.x * UB + threadIdx.x;
+    if (i < n) row2site[i] = h.site[rowslot[i]];
+}
+
+// U5b: fine site -> coarse parent and 2^3 offset
+__global__ void k_parent_off(const int *__restrict__ coords, const int *n_dev, long n_cap, HashView h,
+                             const int *__restrict__ rowslot, int *__restrict__ parent,
+                             int *__restrict__ off)
+{
+    long n = n_dev ? (long)*n_dev : n_cap;
+    long i = (long)blockIdx.x * UB + threadIdx.x;
+    if (i >= n) return;
+    int4 c = ((const int4 *)coords)[i];
+    parent[i] = h.site[rowslot[i]];
+    off[i] = ((c.x & 1) * 2 + (c.y & 1)) * 2 + (c.z & 1);
+}
+
+static int run_unique(const int32_t *coords, const int *n_dev, int64_t n_cap, int shift, void *hash,
+                      int64_t hcap, void *scratch, int64_t scratch_bytes, int32_t *site_coords,
+                      int32_t *n_unique, int **rowslot_out, hipStream_t st)
+{
+    if (scratch_bytes < urn_unique_scratch_bytes(n_cap)) {
+        urn_set_error("unique: scratch too small");
+        return URN_EINVAL;
+    }
+    if ((hcap & (hcap - 1)) != 0 || hcap < 2 * n_cap) {
+        urn_set_error("unique: hash capacity must be a power of two >= 2n");
+        return URN_EINVAL;
+    }
+    HashView h = hash_view(hash, hcap);
+    int *rowslot = (int *)scratch;
+    int *blocksum = (int *)((char *)scratch + ((4 * n_cap + 255) / 256) * 256);
+    int nblk = (int)n_blocks(n_cap);
+    *rowslot_out = rowslot;
+    if (nblk == 0) {
+        (void)hipMemsetAsync(n_unique, 0, 4, st);
+        return URN_OK;
+    }
+    hipLaunchKernelGGL(k_insert, dim3(nblk), dim3(UB), 0, st, coords, n_dev, (long)n_cap, shift, h, rowslot);
+    hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(UB), 0, st, n_dev, (long)n_cap, h, rowslot, blocksum);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blocksum, nblk, n_unique);
+    hipLaunchKernelGGL(k_assign, dim3(nblk), dim3(UB), 0, st, coords, n_dev, (long)n_cap, shift, h, rowslot,
+                       blocksum, site_coords);
+    return URN_OK;
+}
+
+extern "C" int urn_sites_build(const int32_t *coords, int64_t n, int spatial, void *hash, int64_t hcap,
+                               void *scratch, int64_t scratch_bytes, int32_t *row2site,
+                               int32_t *site_coords, int32_t *n_active, void *stream)
+{
+    URN_CHECK_ARG(n >= 0 && hash && scratch && n_active, "null pointer");
+    URN_CHECK_ARG(n == 0 || (coords && row2site && site_coords), "null pointer");
+    URN_CHECK_ARG(spatial > 0 && spatial <= 32768, "spatial size must be in 1..32768");
+    URN_CHECK_ARG(n < 0x7F000000ll, "too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    int *rowslot;
+    int rc = run_unique(coords, nullptr, n, 0, hash, hcap, scratch, scratch_bytes, site_coords, n_active,
+                        &rowslot, st);
+    if (rc) return rc;
+    if (n > 0) {
+        HashView h = hash_view(hash, hcap);
+        hipLaunchKernelGGL(k_row2site, dim3((int)n_blocks(n)), dim3(UB), 0, st, (const int *)nullptr, (long)n,
+                           h, rowslot, row2site);
+    }
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_level_down(const int32_t *fine_coords, const int32_t *n_fine, int64_t n_cap, void *hash,
+                              int64_t hcap, void *scratch, int64_t scratch_bytes,
+                              int32_t *coarse_coords, int32_t *parent, int32_t *off, int32_t *n_coarse,
+                              void *stream)
+{
+    URN_CHECK_ARG(n_cap >= 0 && hash && scratch && n_coarse, "null pointer");
+    URN_CHECK_ARG(n_cap == 0 || (fine_coords && coarse_coords && parent && off), "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int *rowslot;
+    int rc = run_unique(fine_coords, n_fine, n_cap, 1, hash, hcap, scratch, scratch_bytes, coarse_coords,
+                        n_coarse, &rowslot, st);
+    if (rc) return rc;
+    if (n_cap > 0) {
+        HashView h = hash_view(hash, hcap);
+        hipLaunchKernelGGL(k_parent_off, dim3((int)n_blocks(n_cap)), dim3(UB), 0, st, fine_coords, n_fine,
+                           (long)n_cap, h, rowslot, parent, off);
+    }
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+__global__ void k_down_tables(const int *__restrict__ parent, const int *__restrict__ off, const int *n_dev,
+                              long n_cap, int *__restrict__ chd, long ld_c, int *__restrict__ up, long ld_f)
+{
+    long n = n_dev ? (long)*n_dev : n_cap;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int p = parent[i], o = off[i];
+    chd[(long)o * ld_c + p] = (int)i;
+    up[(long)o * ld_f + i] = p;
+}
+
+extern "C" int urn_down_tables(const int32_t *parent, const int32_t *off, const int32_t *n_fine, int64_t n_cap,
+                               int32_t *chd, int64_t ld_c, int32_t *up, int64_t ld_f, void *stream)
+{
+    if (n_cap <= 0) return URN_OK;
+    URN_CHECK_ARG(parent && off && chd && up, "null pointer");
+    hipLaunchKernelGGL(k_down_tables, dim3(urn_cdiv(n_cap, 256)), dim3(256), 0, (hipStream_t)stream, parent, off,
+                       n_fine, (long)n_cap, chd, (long)ld_c, up, (long)ld_f);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// ---- submanifold rulebook -------------------------------------------------------------
+// grid (row blocks, 27): one thread per (site, offset): probe the hash for site + d(o).
+__global__ void k_rulebook_subm(const int *__restrict__ coords, const int *n_dev, long n_cap, int spatial,
+                                HashView h, int *__restrict__ nbr, long ld, int *n_rules)
+{
+    long n = n_dev ? (long)*n_dev : n_cap;
+    long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int o = blockIdx.y;
+    int dx = o / 9 - 1, dy = (o / 3) % 3 - 1, dz = o % 3 - 1;
+    int v = -1;
+    if (j < n) {
+        int4 c = ((const int4 *)coords)[j];
+        int x = c.x + dx, y = c.y + dy, z = c.z + dz;
+        if (x >= 0 && y >= 0 && z >= 0 && x < spatial && y < spatial && z < spatial) {
+            unsigned long long key = urn_key(x, y, z, c.w);
+            unsigned long long s = urn_mix(key) & h.mask;
+            for (;;) {
+                unsigned long long k = h.keys[s];
+                if (k == key) { v = h.site[s]; break; }
+                if (k == URN_EMPTY_KEY) break;
+                s = (s + 1) & h.mask;
+            }
+        }
+        nbr[(long)o * ld + j] = v;
+    }
+    if (n_rules) {
+        unsigned long long b = __ballot(v >= 0);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_rules, __popcll(b));
+    }
+}
+
+extern "C" int urn_rulebook_subm(const int32_t *site_coords, const int32_t *n_dev, int64_t n_cap, int spatial,
+                                 const void *hash, int64_t hcap, int32_t *nbr, int64_t ld, int32_t *n_rules,
+                                 void *stream)
+{
+    if (n_cap <= 0) return URN_OK;
+    URN_CHECK_ARG(site_coords && hash && nbr, "null pointer");
+    URN_CHECK_ARG(ld >= n_cap, "ld < n_cap");
+    HashView h = hash_view((void *)hash, hcap);
+    hipLaunchKernelGGL(k_rulebook_subm, dim3(urn_cdiv(n_cap, 256), 27), dim3(256), 0, (hipStream_t)stream,
+                       site_coords, n_dev, (long)n_cap, spatial, h, nbr, (long)ld, n_rules);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// ---- InputLayer feature merge (mode 3: sum duplicates) ---------------------------------
+__global__ void k_feat_accum(const float *__restrict__ feats, const int *__restrict__ row2site, long n, int nf,
+                             double *__restrict__ acc)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nf) return;
+    long i = t / nf;
+    int f = (int)(t - i * nf);
+    atomicAdd(&acc[(long)row2site[i] * nf + f], (double)feats[t]);
+}
+
+__global__ void k_feat_round(const double *__restrict__ acc, const int *n_dev, long n_cap, int nf,
+                             float *__restrict__ out)
+{
+    long n = n_dev ? (long)*n_dev : n_cap;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n * nf) out[t] = (float)acc[t];
+}
+
+extern "C" int urn_input_features(const float *feats, const int32_t *row2site, int64_t n, int nf,
+                                  const int32_t *n_active, int64_t n_cap, double *acc64, float *site_feats,
+                                  void *stream)
+{
+    if (n <= 0) return URN_OK;
+    URN_CHECK_ARG(feats && row2site && acc64 && site_feats && nf > 0, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(acc64, 0, (size_t)(n_cap * nf) * 8, st) != hipSuccess) {
+        urn_set_error("urn_input_features: memset failed");
+        return URN_EHIP;
+    }
+    hipLaunchKernelGGL(k_feat_accum, dim3(urn_cdiv(n * nf, 256)), dim3(256), 0, st, feats, row2site, (long)n, nf,
+                       acc64);
+    hipLaunchKernelGGL(k_feat_round, dim3(urn_cdiv(n_cap * nf, 256)), dim3(256), 0, st, acc64, n_active,
+                       (long)n_cap, nf, site_feats);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}

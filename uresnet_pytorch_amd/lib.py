@@ -1,0 +1,89 @@
+"""ctypes binding of liburesnet_hip.so (C ABI declared in include/uresnet_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails,
+a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liburesnet_hip.so')
+_lib = None
+
+c_void_p, c_int, c_i64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+
+# name -> (restype, argtypes); must list every symbol of include/uresnet_hip.h
+SIGNATURES = {
+    'urn_version': (c_int, []),
+    'urn_last_error': (ctypes.c_char_p, []),
+    'urn_hash_capacity': (c_i64, [c_i64]),
+    'urn_hash_bytes': (c_i64, [c_i64]),
+    'urn_unique_scratch_bytes': (c_i64, [c_i64]),
+    'urn_hash_clear': (c_int, [c_void_p, c_i64, c_void_p]),
+    'urn_sites_build': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    'urn_input_features': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_i64, c_void_p, c_void_p,
+                                   c_void_p]),
+    'urn_rulebook_subm': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p,
+                                  c_void_p]),
+    'urn_level_down': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
+    'urn_down_tables': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
+    'urn_fill_i32': (c_int, [c_void_p, c_i64, ctypes.c_int32, c_void_p]),
+    'urn_gconv_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_int, c_int, c_void_p,
+                              c_void_p, c_void_p]),
+    'urn_gconv_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p,
+                                 c_void_p]),
+    'urn_transpose_w': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'urn_bn_scratch_bytes': (c_i64, [c_int]),
+    'urn_bn_relu_fwd': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
+    'urn_bn_relu_apply': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_void_p]),
+    'urn_bn_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    'urn_rows_scatter_add': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+}
+
+
+def load():
+    """Load the shared library and bind every entry point (no GPU needed)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('liburesnet_hip.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                               '(expected at %s)' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().urn_last_error()
+        raise RuntimeError('liburesnet_hip %s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'non-contiguous tensor handed to the C ABI'
+    return t.data_ptr()
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError('uresnet_pytorch_amd: the HIP path needs tensors on the GPU (got %s); '
+                           'there is no CPU fallback' % t.device)

@@ -1,0 +1,72 @@
+"""Sparse U-ResNet behind the reference's nn.Module surface.
+
+Mirrors reference uresnet/models/uresnet_sparse.py:7-82 (class names, constructor
+signature, forward contract, loss semantics); the `sparseconvnet` calls are served
+by uresnet_pytorch_amd.scn, i.e. hand-written gfx950 kernels behind the C ABI.
+"""
+import torch
+
+from .. import scn
+
+
+class UResNet(torch.nn.Module):
+    def __init__(self, flags):
+        super(UResNet, self).__init__()
+        self._flags = flags
+        dimension = flags.DATA_DIM
+        reps = 2          # conv block repetition factor       (reference :13)
+        kernel_size = 2   # strided conv filter size           (reference :14)
+        m = flags.URESNET_FILTERS
+        nPlanes = [i * m for i in range(1, flags.URESNET_NUM_STRIDES + 1)]   # linear widths (reference :16)
+        nInputFeatures = 1
+        self.sparseModel = scn.Sequential().add(
+            scn.InputLayer(dimension, flags.SPATIAL_SIZE, mode=3)).add(
+            scn.SubmanifoldConvolution(dimension, nInputFeatures, m, 3, False)).add(
+            scn.UNet(dimension, reps, nPlanes, residual_blocks=True, downsample=[kernel_size, 2])).add(
+            scn.BatchNormReLU(m)).add(
+            scn.OutputLayer(dimension))
+        self.sparseModel[0].num_levels = len(nPlanes)   # build every strided level in one integer phase
+        self.linear = torch.nn.Linear(m, flags.NUM_CLASS)
+
+    def forward(self, point_cloud):
+        """point_cloud: (N, d+2) rows [x, y, z, batch_id, value]; returns [ (N, NUM_CLASS) ]."""
+        coords = point_cloud[:, 0:-1].float()
+        features = point_cloud[:, -1][:, None].float()
+        x = self.sparseModel((coords, features))
+        x = self.linear(x)
+        return [x]
+
+
+class SegmentationLoss(torch.nn.modules.loss._Loss):
+    """Per-GPU-entry, per-event mean voxel cross-entropy, SUMMED over events
+    (reference uresnet_sparse.py:46-82).  Returns (loss tensor, accuracy sum)."""
+
+    def __init__(self, flags, reduction='sum'):
+        super(SegmentationLoss, self).__init__(reduction=reduction)
+        self._flags = flags
+        self.cross_entropy = torch.nn.CrossEntropyLoss(reduction='none')
+
+    def forward(self, segmentation, data, label, weight):
+        assert len(segmentation) == len(data)
+        assert len(data) == len(label)
+        if weight is not None:
+            assert len(data) == len(weight)
+        total_loss = 0
+        total_acc = 0
+        for i in range(len(segmentation)):
+            batch_ids = data[i][:, -2]
+            # one pass over events without a host sync per event: per-event means via index_add
+            ids, inv = torch.unique(batch_ids, return_inverse=True)
+            nev = ids.numel()
+            event_label = torch.squeeze(label[i], dim=-1).long()
+            loss_seg = self.cross_entropy(segmentation[i], event_label)
+            if weight is not None:
+                loss_seg = loss_seg * torch.squeeze(weight[i], dim=-1).float()
+            cnt = torch.zeros(nev, device=loss_seg.device, dtype=loss_seg.dtype).index_add_(
+                0, inv, torch.ones_like(loss_seg))
+            per_event = torch.zeros(nev, device=loss_seg.device, dtype=loss_seg.dtype).index_add_(0, inv, loss_seg)
+            total_loss = total_loss + (per_event / cnt).sum()
+            correct = (torch.argmax(segmentation[i], dim=-1) == event_label).to(loss_seg.dtype)
+            acc = torch.zeros(nev, device=loss_seg.device, dtype=loss_seg.dtype).index_add_(0, inv, correct)
+            total_acc = total_acc + (acc / cnt).sum()
+        return total_loss, float(total_acc)

@@ -1,0 +1,224 @@
+"""Host side of the sparse path: geometry (integer phase) and autograd Functions that
+call the HIP kernels through the C ABI.  PyTorch only owns memory and the stream.
+"""
+import torch
+
+from . import lib as _l
+
+
+class SparseGeometry:
+    """Active sites, hash tables and gather tables of every level of one forward.
+
+    Built entirely on the device (coordinate hash + rulebooks, no host work); one
+    device->host copy of the per-level site counts ends the integer phase so that the
+    float phase can size its tensors.  Restates the metadata that scn.InputLayer /
+    SubmanifoldConvolution / Convolution build on the host in the reference
+    (uresnet/models/uresnet_sparse.py:20-22).
+    """
+
+    def __init__(self, coords, spatial_size, num_levels=1):
+        _l.require_gpu(coords)
+        L = _l.load()
+        assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+        coords = coords.contiguous()
+        dev = coords.device
+        self.device = dev
+        self.spatial = int(spatial_size)
+        self.num_levels = int(num_levels)
+        N = coords.shape[0]
+        self.n_rows = N
+        cap = max(N, 1)
+        self.cap = cap
+        st = _l.stream()
+        hcap = L.urn_hash_capacity(cap)
+        hbytes = L.urn_hash_bytes(hcap)
+        self.hcap = hcap
+        # one arena for all level hashes, cleared with a single memset
+        self.hash = torch.empty(self.num_levels * hbytes, dtype=torch.uint8, device=dev)
+        _l.check(L.urn_hash_clear(self.hash.data_ptr(), self.hash.numel(), st), 'hash_clear')
+        self._hptr = [self.hash.data_ptr() + l * hbytes for l in range(self.num_levels)]
+        sbytes = L.urn_unique_scratch_bytes(cap)
+        scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        # counts: [n_l for each level] + [rules_l for each level]
+        self.counts = torch.zeros(2 * self.num_levels, dtype=torch.int32, device=dev)
+        cptr = self.counts.data_ptr()
+        self.row2site = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.coords = [torch.empty((cap, 4), dtype=torch.int32, device=dev)]
+        _l.check(L.urn_sites_build(coords.data_ptr(), N, self.spatial, self._hptr[0], hcap, scratch.data_ptr(),
+                                   sbytes, self.row2site.data_ptr(), self.coords[0].data_ptr(), cptr, st),
+                 'sites_build')
+        self.ld = cap                      # leading dimension of every gather table
+        self.nbr, self.parent, self.off, self.chd, self.up = [], [], [], [], []
+        sp = self.spatial
+        # strided tables are filled with -1 by one launch
+        if self.num_levels > 1:
+            self._strided = torch.empty((self.num_levels - 1, 2, 8, cap), dtype=torch.int32, device=dev)
+            _l.check(L.urn_fill_i32(self._strided.data_ptr(), self._strided.numel(), -1, st), 'fill')
+        self._nbr_all = torch.empty((self.num_levels, 27, cap), dtype=torch.int32, device=dev)
+        for l in range(self.num_levels):
+            n_dev = cptr + 4 * l
+            if l + 1 < self.num_levels:
+                cc = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+                parent = torch.empty(cap, dtype=torch.int32, device=dev)
+                off = torch.empty(cap, dtype=torch.int32, device=dev)
+                _l.check(L.urn_level_down(self.coords[l].data_ptr(), n_dev, cap, self._hptr[l + 1], hcap,
+                                          scratch.data_ptr(), sbytes, cc.data_ptr(), parent.data_ptr(),
+                                          off.data_ptr(), cptr + 4 * (l + 1), st), 'level_down')
+                chd, up = self._strided[l, 0], self._strided[l, 1]
+                _l.check(L.urn_down_tables(parent.data_ptr(), off.data_ptr(), n_dev, cap, chd.data_ptr(), cap,
+                                           up.data_ptr(), cap, st), 'down_tables')
+                self.coords.append(cc); self.parent.append(parent); self.off.append(off)
+                self.chd.append(chd); self.up.append(up)
+            nbr = self._nbr_all[l]
+            _l.check(L.urn_rulebook_subm(self.coords[l].data_ptr(), n_dev, cap, sp, self._hptr[l], hcap,
+                                         nbr.data_ptr(), cap, cptr + 4 * (self.num_levels + l), st),
+                     'rulebook_subm')
+            self.nbr.append(nbr)
+            sp = (sp + 1) // 2
+        self._scratch = scratch
+        host = self.counts.cpu().tolist()       # the one sync of the integer phase
+        self.n = host[:self.num_levels]
+        self.rules = host[self.num_levels:]
+
+    # canonical exports for parity tests (device -> host)
+    def export_nbr(self, level):
+        return self.nbr[level][:, :self.n[level]].cpu().numpy()
+
+    def export_coords(self, level):
+        return self.coords[level][:self.n[level]].cpu().numpy()
+
+
+def input_features(geo, feats):
+    """InputLayer mode 3: site features = sum of the rows that share a site."""
+    L = _l.load()
+    feats = feats.contiguous().float()
+    nf = feats.shape[1]
+    n0 = geo.n[0]
+    out = torch.empty((n0, nf), dtype=torch.float32, device=feats.device)
+    acc = torch.empty(max(n0 * nf, 1), dtype=torch.float64, device=feats.device)
+    _l.check(L.urn_input_features(feats.data_ptr(), geo.row2site.data_ptr(), geo.n_rows, nf, None, n0,
+                                  acc.data_ptr(), out.data_ptr(), _l.stream()), 'input_features')
+    return out
+
+
+def _gconv(x, wt, tbl, ld, K, flip, n_out, cin, cout, res=None):
+    L = _l.load()
+    y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    _l.check(L.urn_gconv_fwd(_l.ptr(x), _l.ptr(wt), tbl.data_ptr(), ld, K, flip, n_out, cin, cout, _l.ptr(res),
+                             y.data_ptr(), _l.stream()), 'gconv_fwd')
+    return y
+
+
+def _transpose_w(w):
+    L = _l.load()
+    K, a, b = w.shape
+    wt = torch.empty((K, b, a), dtype=torch.float32, device=w.device)
+    _l.check(L.urn_transpose_w(_l.ptr(w), K, a, b, wt.data_ptr(), _l.stream()), 'transpose_w')
+    return wt
+
+
+class GConvFunction(torch.autograd.Function):
+    """y = gather-conv(x, W) (+ res).  tbl_f / tbl_b are the forward and the inverse
+    gather tables ([K][ld]); flip_b mirrors the offset index in the backward table
+    (submanifold: the inverse of nbr[o] is nbr[26-o])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, res, tbl_f, tbl_b, flip_b, ld, n_out, n_in):
+        _l.require_gpu(x)
+        x = x.contiguous(); weight = weight.contiguous()
+        K, cin, cout = weight.shape
+        assert x.shape == (n_in, cin), (x.shape, n_in, cin)
+        wt = _transpose_w(weight)
+        y = _gconv(x, wt, tbl_f, ld, K, 0, n_out, cin, cout, None if res is None else res.contiguous())
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (tbl_f, tbl_b, flip_b, ld, n_out, n_in, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        tbl_f, tbl_b, flip_b, ld, n_out, n_in, has_res = ctx.meta
+        K, cin, cout = weight.shape
+        dy = dy.contiguous()
+        L = _l.load()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dx[i] = sum_o dy[inv[o][i]] @ W[o]^T : same kernel, W itself is the
+            # "(K, cout_eff=cin, cin_eff=cout)" transposed operand
+            dx = _gconv(dy, weight, tbl_b, ld, K, flip_b, n_in, cout, cin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(weight)
+            _l.check(L.urn_gconv_bwd_dw(_l.ptr(x), _l.ptr(dy), tbl_f.data_ptr(), ld, K, n_out, cin, cout,
+                                        dw.data_ptr(), _l.stream()), 'gconv_bwd_dw')
+        dres = dy if (has_res and ctx.needs_input_grad[2]) else None
+        return dx, dw, dres, None, None, None, None, None, None
+
+
+class BNReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, training):
+        _l.require_gpu(x)
+        L = _l.load()
+        x = x.contiguous()
+        n, c = x.shape
+        y = torch.empty_like(x)
+        st = _l.stream()
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+            scratch = torch.empty(L.urn_bn_scratch_bytes(c), dtype=torch.uint8, device=x.device)
+            _l.check(L.urn_bn_relu_fwd(_l.ptr(x), n, c, _l.ptr(gamma), _l.ptr(beta), float(eps), int(relu),
+                                       y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _l.ptr(running_mean),
+                                       _l.ptr(running_var), float(momentum), scratch.data_ptr(), st), 'bn_fwd')
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+            _l.check(L.urn_bn_relu_apply(_l.ptr(x), n, c, _l.ptr(gamma), _l.ptr(beta), _l.ptr(mean),
+                                         _l.ptr(invstd), int(relu), y.data_ptr(), st), 'bn_apply')
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu = int(relu)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError('BatchNormReLU backward in eval mode is not supported')
+        L = _l.load()
+        n, c = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(L.urn_bn_scratch_bytes(c), dtype=torch.uint8, device=x.device)
+        _l.check(L.urn_bn_relu_bwd(_l.ptr(x), _l.ptr(y), _l.ptr(dy), n, c, _l.ptr(gamma), _l.ptr(mean),
+                                   _l.ptr(invstd), ctx.relu, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                   scratch.data_ptr(), _l.stream()), 'bn_bwd')
+        return dx, dg, db, None, None, None, None, None, None
+
+
+class RowsGatherFunction(torch.autograd.Function):
+    """OutputLayer: y[i] = x[idx[i]]"""
+
+    @staticmethod
+    def forward(ctx, x, idx, n_rows):
+        _l.require_gpu(x)
+        L = _l.load()
+        x = x.contiguous()
+        c = x.shape[1]
+        y = torch.empty((n_rows, c), dtype=torch.float32, device=x.device)
+        _l.check(L.urn_rows_gather(_l.ptr(x), idx.data_ptr(), n_rows, c, y.data_ptr(), _l.stream()), 'rows_gather')
+        ctx.idx = idx
+        ctx.shape = (x.shape[0], c, n_rows)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _l.load()
+        na, c, n_rows = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.zeros((na, c), dtype=torch.float32, device=dy.device)
+        _l.check(L.urn_rows_scatter_add(_l.ptr(dy), ctx.idx.data_ptr(), n_rows, c, dx.data_ptr(), _l.stream()),
+                 'rows_scatter_add')
+        return dx, None, None
