@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- active-voxels/sec of one sparse U-ResNet training step (forward + loss +
+backward + gradient all-reduce + Adam step) on N MI355X GPUs of one node.
+
+Workload at N=1: BASELINE.json configs[2]: uresnet_sparse -dd 3 -ss 512, one event of
+50,000 active voxels, -nc 5 -uf 16 -uns 5, fp32.  Weak scaling: every rank processes its
+own event(s) (rank r uses generator seeds r*E .. r*E+E-1), so whole-job voxels grow with N.
+Inputs are synthetic (SURVEY App. D generator) and resident in HBM before timing starts.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (gather-conv MFMA kernel, forward + input-gradient launches):
+                  algorithmic FLOPs (2*R*Cin*Cout per launch, R = rules of that launch) divided by
+                  the kernel's launch durations measured with HIP events on the launch stream;
+  cpu_baseline -- the CPU oracle (oracle/, a port: the reference's own sparse path cannot run
+                  without sparseconvnet) timed on the host cores on one full step of the same event.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+SPATIAL, VOXELS, FILTERS, STRIDES, NCLASS = 512, 50000, 16, 5, 5
+
+
+def conv_launch_flops(model, geo):
+    """Algorithmic FLOPs of every gather-conv MFMA launch (forward + dX) of one step."""
+    from uresnet_pytorch_amd import scn
+    total, launches = 0.0, 0
+
+    def rules(mod, level_in):
+        if isinstance(mod, scn.SubmanifoldConvolution):
+            return geo.rules[level_in]
+        if isinstance(mod, scn.NetworkInNetwork):
+            return geo.n[level_in]
+        return None
+
+    # walk the module tree with the level each module runs at
+    def walk(mod, level):
+        nonlocal total, launches
+        if isinstance(mod, (scn.SubmanifoldConvolution, scn.NetworkInNetwork)):
+            cin, cout = mod.nIn, mod.nOut
+            if cin % 16 == 0 and cout % 16 == 0:
+                total += 2 * (2.0 * rules(mod, level) * cin * cout); launches += 2   # fwd + dX
+            return level
+        if isinstance(mod, scn.Convolution):
+            total += 2 * (2.0 * geo.n[level] * mod.nIn * mod.nOut); launches += 2
+            return level + 1
+        if isinstance(mod, scn.Deconvolution):
+            total += 2 * (2.0 * geo.n[level - 1] * mod.nIn * mod.nOut); launches += 2
+            return level - 1
+        if isinstance(mod, scn.ConcatTable):
+            out = level
+            for c in mod.children():
+                out = walk(c, level)
+            return out
+        if isinstance(mod, torch.nn.Sequential):
+            for c in mod.children():
+                level = walk(c, level)
+            return level
+        return level
+
+    walk(model.sparseModel, 0)
+    return total, launches
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--events-per-gpu', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from types import SimpleNamespace
+    from uresnet_pytorch_amd import lib as urn_lib
+    from uresnet_pytorch_amd import parallel
+    from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
+    from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
+
+    rank, world, local_rank = parallel.init_distributed()
+    assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    L = urn_lib.load()
+
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=FILTERS, URESNET_NUM_STRIDES=STRIDES, SPATIAL_SIZE=SPATIAL,
+                            NUM_CLASS=NCLASS)
+    torch.manual_seed(0)
+    model = SparseUResNet(flags).to(dev).train()
+    parallel.broadcast_parameters(model)
+    crit = SparseSegmentationLoss(flags)
+    E = args.events_per_gpu
+    blob = make_sparse_blob([rank * E + e for e in range(E)], SPATIAL, VOXELS)
+    data = torch.from_numpy(blob['data']).to(dev)
+    label = torch.from_numpy(blob['label']).to(dev)
+    grads = parallel.FlatGradients(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    voxels_per_rank = int(data.shape[0])
+
+    def step():
+        grads.zero()
+        out = model(data)
+        loss, _ = crit(out, [data], [label], None)
+        loss.backward()
+        grads.all_reduce()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    ms_per_step = 1e3 * dt / args.steps
+    total_voxels = voxels_per_rank * world
+    value = total_voxels * args.steps / dt
+
+    result = None
+    if rank == 0:
+        # roofline leg: instrumented steps after the timed region (HIP events on the launch stream)
+        from uresnet_pytorch_amd import sparse_ops as so
+        geo = so.SparseGeometry(data[:, :4].to(torch.int32), SPATIAL, STRIDES)
+        flops_step, launches_step = conv_launch_flops(model, geo)
+        PSTEPS = 3
+        urn_lib.check(L.urn_prof_enable(1))
+        for _ in range(PSTEPS):
+            step()
+        torch.cuda.synchronize()
+        ms = ctypes.c_double(); n = ctypes.c_int64()
+        urn_lib.check(L.urn_prof_read(0, ctypes.byref(ms), ctypes.byref(n)))
+        urn_lib.check(L.urn_prof_enable(0))
+        achieved = (flops_step * PSTEPS) / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        roofline = {
+            'bound': 'mfma', 'kernel': 'k_gconv_fwd<MB,NB> (gather-conv forward + input-gradient)',
+            'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None,
+            'launches_per_step': int(n.value // PSTEPS), 'avg_launch_us': round(1e3 * ms.value / max(n.value, 1), 2),
+            'algorithmic_gflop_per_step': round(flops_step / 1e9, 3),
+        }
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import sparse_oracle as orc
+            P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if 'running' not in k}
+            ref = orc.SparseUResNetOracle(P, FILTERS, STRIDES, NCLASS, SPATIAL)
+            t1 = time.perf_counter()
+            logits = ref.forward(blob['data'])
+            _, _, dl = orc.segmentation_loss(logits, blob['data'], blob['label'])
+            ref.backward(dl)
+            cdt = time.perf_counter() - t1
+            cpu = {'value': round(voxels_per_rank / cdt, 1), 'unit': 'active-voxels/s',
+                   'cores': int(orc.lib().orc_num_threads()), 'kind': 'port',
+                   'sample': '1 full fwd+bwd step of the same %d-voxel event(s) (%.2f s)' % (voxels_per_rank, cdt)}
+        result = {
+            'metric': 'active-voxels/sec fwd+bwd, 512^3 sparse 5-class U-ResNet', 'value': round(value, 1),
+            'unit': 'active-voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'uresnet_sparse -dd 3 -ss 512 -nc 5 -uf 16 -uns 5, %d event(s)/GPU x %d active voxels, '
+                                   'fp32, step = fwd+loss+bwd+grad all-reduce(SUM)+Adam' % (E, VOXELS),
+                       'events_per_gpu': E, 'voxels_per_event': VOXELS, 'parallelism': 'dp%d (events sharded, '
+                       'one RCCL all-reduce per step)' % world},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

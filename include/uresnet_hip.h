@@ -125,6 +125,13 @@ int urn_rows_gather(const float *x, const int32_t *idx, int64_t n, int c, float 
 int urn_rows_scatter_add(const float *dy, const int32_t *idx, int64_t n, int c, float *dx,
                          void *stream);
 
+/* ----------------------------------------------------------------------- measurement
+ * Optional per-kernel timing (HIP events on the launch stream), off by default.
+ * kind 0 = gather-conv forward/input-gradient kernel, 1 = weight-gradient kernel.
+ * urn_prof_enable resets the records; urn_prof_read waits for the recorded events. */
+int urn_prof_enable(int on);
+int urn_prof_read(int kind, double *total_ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

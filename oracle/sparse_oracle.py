@@ -263,6 +263,8 @@ class SparseUResNetOracle:
     def _bn(self, prefix, x):
         g, b = self.P[prefix + '.weight'], self.P[prefix + '.bias']
         y, mean, invstd = bn_relu_fwd(x, g, b, True)
+        if getattr(self, 'keep_acts', False):
+            self.acts[prefix] = y
 
         def back(dy):
             dx, dg, db = bn_relu_bwd(x, y, dy, g, mean, invstd, True)
@@ -331,6 +333,7 @@ class SparseUResNetOracle:
         feats = pc[:, 4:5].astype(np.float32)
         self.geo = geo = Geometry(coords, feats, self.spatial, self.L, mode=3)
         self.G = {}
+        self.acts = {}
         x, b_stem = self._conv('sparseModel.1.weight', geo.feats, geo.nbr[0], geo.nbr_inv[0])
         x, b_u = self._U('sparseModel.2', 0, x)
         x, b_bn = self._bn('sparseModel.3', x)

@@ -1,143 +1,228 @@
 // BatchNorm(+ReLU) over the active-row matrix, and the OutputLayer row gather.
-// HBM-bound passes: coalesced streaming reads, fp64 per-thread accumulation,
-// fixed-order two-stage column reduction (deterministic), one write.
+// HBM-bound passes: 16-byte coalesced streaming reads with several rows in flight per
+// lane, fp64 per-thread accumulation, fixed-order two-stage column reduction
+// (deterministic), one 16-byte write per lane.
 // Replaces scn.BatchNormReLU / scn.BatchNormLeakyReLU(leak 0) and scn.OutputLayer
 // (reference uresnet/models/uresnet_sparse.py:22-24).
 #include "urn_common.h"
 
-#define BN_MAXBLK 256
+#define BN_MAXBLK 1024
 
-extern "C" int64_t urn_bn_scratch_bytes(int c) { return (int64_t)BN_MAXBLK * 2 * c * 8 + 256; }
+extern "C" int64_t urn_bn_scratch_bytes(int c) { return (int64_t)(BN_MAXBLK + 1) * 2 * c * 8 + 256; }
 
 // mode 0: (sum x, sum x^2); mode 1: (sum g, sum g*xhat) with g = dy * (relu ? y>0 : 1)
-template <int MODE>
+// VEC = 4: each lane owns 4 consecutive columns (c % 4 == 0, c <= 1024); VEC = 1: scalar columns (c <= 256)
+template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x, const float *__restrict__ y,
                                                     const float *__restrict__ dy,
                                                     const float *__restrict__ mean,
                                                     const float *__restrict__ invstd, long n, int c, int relu,
                                                     long rows_per_block, double *__restrict__ part)
 {
-    __shared__ double s0[256], s1[256];
+    __shared__ double s0[256 * VEC], s1[256 * VEC];
     const int t = threadIdx.x;
-    const int c0 = blockIdx.y * 256;
-    const int cw = min(256, c - c0);
-    const int R = 256 / cw;
-    const int col = c0 + t % cw, rsub = t / cw;
+    const int cw = c / VEC;          // lanes per row
+    const int R = 256 / cw;          // rows per pass
+    const int cg = t % cw, rsub = t / cw;
     const bool active = t < R * cw;
     const long row_begin = (long)blockIdx.x * rows_per_block;
     const long row_end = min(n, row_begin + rows_per_block);
-    double a0 = 0.0, a1 = 0.0;
+    double a0[VEC], a1[VEC];
+    float mu[VEC], is[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        a0[k] = 0.0; a1[k] = 0.0;
+        mu[k] = 0.f; is[k] = 0.f;
+        if (MODE == 1 && active) { mu[k] = mean[cg * VEC + k]; is[k] = invstd[cg * VEC + k]; }
+    }
     if (active) {
-        float mu = 0.f, is = 0.f;
-        if (MODE == 1) { mu = mean[col]; is = invstd[col]; }
-        for (long row = row_begin + rsub; row < row_end; row += R) {
-            long e = row * c + col;
-            if (MODE == 0) {
-                double v = (double)x[e];
-                a0 += v;
-                a1 += v * v;
-            } else {
-                float g = dy[e];
-                if (relu && !(y[e] > 0.f)) g = 0.f;
-                double xh = ((double)x[e] - (double)mu) * (double)is;
-                a0 += (double)g;
-                a1 += (double)g * xh;
+        constexpr int U = 4;  // rows in flight per lane
+        for (long row = row_begin + rsub; row < row_end; row += (long)U * R) {
+            float vx[U][VEC], vy[U][VEC], vd[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                long rr = row + (long)u * R;
+                bool ok = rr < row_end;
+                long e = rr * c + cg * VEC;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { vx[u][k] = 0.f; vy[u][k] = 0.f; vd[u][k] = 0.f; }
+                if (ok) {
+                    if (VEC == 4) {
+                        f32x4 v = *(const f32x4 *)(x + e);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) vx[u][k] = v[k];
+                        if (MODE == 1) {
+                            f32x4 w = *(const f32x4 *)(dy + e);
+                            f32x4 z = *(const f32x4 *)(y + e);
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) { vd[u][k] = w[k]; vy[u][k] = z[k]; }
+                        }
+                    } else {
+                        vx[u][0] = x[e];
+                        if (MODE == 1) { vd[u][0] = dy[e]; vy[u][0] = y[e]; }
+                    }
+                }
+                if (MODE == 1 && !ok) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) vx[u][k] = mu[k];  // xhat = 0, g = 0
+                }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (MODE == 0) {
+                        double v = (double)vx[u][k];
+                        a0[k] += v;
+                        a1[k] += v * v;
+                    } else {
+                        float g = vd[u][k];
+                        if (relu && !(vy[u][k] > 0.f)) g = 0.f;
+                        double xh = ((double)vx[u][k] - (double)mu[k]) * (double)is[k];
+                        a0[k] += (double)g;
+                        a1[k] += (double)g * xh;
+                    }
+                }
         }
     }
-    s0[t] = a0; s1[t] = a1;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { s0[k * 256 + t] = a0[k]; s1[k * 256 + t] = a1[k]; }
     __syncthreads();
     if (t < cw) {
-        double r0 = 0.0, r1 = 0.0;
-        for (int k = 0; k < R; ++k) { r0 += s0[k * cw + t]; r1 += s1[k * cw + t]; }
-        part[((long)blockIdx.x * 2 + 0) * c + col] = r0;
-        part[((long)blockIdx.x * 2 + 1) * c + col] = r1;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            double r0 = 0.0, r1 = 0.0;
+            for (int j = 0; j < R; ++j) { r0 += s0[k * 256 + j * cw + t]; r1 += s1[k * 256 + j * cw + t]; }
+            part[((long)blockIdx.x * 2 + 0) * c + t * VEC + k] = r0;
+            part[((long)blockIdx.x * 2 + 1) * c + t * VEC + k] = r1;
+        }
     }
 }
 
-__global__ void k_bn_finalize_fwd(const double *__restrict__ part, int nblk, long n, int c, double eps,
-                                  float *__restrict__ mean, float *__restrict__ invstd,
-                                  float *running_mean, float *running_var, double momentum)
+// Second stage: 16 columns per block, 16 lanes per column sweep the block partials in a fixed order.
+// mode 0 -> mean/invstd (+ running stats); mode 1 -> dgamma/dbeta and the two backward coefficients.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bn_finalize(const double *__restrict__ part, int nblk, long n, int c,
+                                                     double eps, float *__restrict__ o0, float *__restrict__ o1,
+                                                     float *r0p, float *r1p, double momentum)
 {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((long)b * 2) * c + col]; ss += part[((long)b * 2 + 1) * c + col]; }
-    double m = n > 0 ? s / (double)n : 0.0;
-    double v = n > 0 ? ss / (double)n - m * m : 0.0;
-    if (v < 0.0) v = 0.0;
-    mean[col] = (float)m;
-    invstd[col] = (float)(1.0 / sqrt(v + eps));
-    if (running_mean) running_mean[col] = (float)(momentum * running_mean[col] + (1.0 - momentum) * m);
-    if (running_var) running_var[col] = (float)(momentum * running_var[col] + (1.0 - momentum) * v);
+    __shared__ double s0[256], s1[256];
+    const int t = threadIdx.x, cl = t & 15, bg = t >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (col < c)
+        for (int b = bg; b < nblk; b += 16) {
+            a0 += part[((long)b * 2) * c + col];
+            a1 += part[((long)b * 2 + 1) * c + col];
+        }
+    s0[t] = a0; s1[t] = a1;
+    __syncthreads();
+    if (t < 16 && col < c) {
+        double v0 = 0.0, v1 = 0.0;
+        for (int j = 0; j < 16; ++j) { v0 += s0[j * 16 + t]; v1 += s1[j * 16 + t]; }
+        if (MODE == 0) {
+            double m = n > 0 ? v0 / (double)n : 0.0;
+            double v = n > 0 ? v1 / (double)n - m * m : 0.0;
+            if (v < 0.0) v = 0.0;
+            o0[col] = (float)m;
+            o1[col] = (float)(1.0 / sqrt(v + eps));
+            if (r0p) r0p[col] = (float)(momentum * r0p[col] + (1.0 - momentum) * m);
+            if (r1p) r1p[col] = (float)(momentum * r1p[col] + (1.0 - momentum) * v);
+        } else {
+            double invn = n > 0 ? 1.0 / (double)n : 0.0;
+            o1[col] = (float)v0;            // dbeta
+            o0[col] = (float)v1;            // dgamma
+            r0p[col] = (float)(v0 * invn);  // coef[0][col]
+            r1p[col] = (float)(v1 * invn);  // coef[1][col]
+        }
+    }
 }
 
+template <int VEC>
 __global__ void k_bn_apply_fwd(const float *__restrict__ x, long total, int c, const float *__restrict__ gamma,
                                const float *__restrict__ beta, const float *__restrict__ mean,
                                const float *__restrict__ invstd, int relu, float *__restrict__ y)
 {
-    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= total) return;  // c % 4 == 0 so a float4 never straddles rows
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (i >= total) return;  // c % VEC == 0 so a vector never straddles rows
     int col = (int)(i % c);
-    f32x4 v = *(const f32x4 *)(x + i), o;
+    float v[VEC], o[VEC];
+    if (VEC == 4) {
+        f32x4 t = *(const f32x4 *)(x + i);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < VEC; ++k) v[k] = t[k];
+    } else {
+        v[0] = x[i];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
         float a = gamma[col + k] * invstd[col + k];
         float u = fmaf(v[k] - mean[col + k], a, beta[col + k]);
         o[k] = (relu && u < 0.f) ? 0.f : u;
     }
-    *(f32x4 *)(y + i) = o;
+    if (VEC == 4) {
+        f32x4 t;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) t[k] = o[k];
+        *(f32x4 *)(y + i) = t;
+    } else {
+        y[i] = o[0];
+    }
 }
 
-__global__ void k_bn_apply_fwd_scalar(const float *__restrict__ x, long total, int c,
-                                      const float *__restrict__ gamma, const float *__restrict__ beta,
-                                      const float *__restrict__ mean, const float *__restrict__ invstd,
-                                      int relu, float *__restrict__ y)
+template <int VEC>
+__global__ void k_bn_apply_bwd(const float *__restrict__ x, const float *__restrict__ y,
+                               const float *__restrict__ dy, long total, int c,
+                               const float *__restrict__ gamma, const float *__restrict__ mean,
+                               const float *__restrict__ invstd, const float *__restrict__ coef, int relu,
+                               float *__restrict__ dx)
 {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= total) return;
     int col = (int)(i % c);
-    float u = fmaf(x[i] - mean[col], gamma[col] * invstd[col], beta[col]);
-    y[i] = (relu && u < 0.f) ? 0.f : u;
+    float vx[VEC], vy[VEC], vd[VEC], o[VEC];
+    if (VEC == 4) {
+        f32x4 a = *(const f32x4 *)(x + i), b = *(const f32x4 *)(y + i), d = *(const f32x4 *)(dy + i);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { vx[k] = a[k]; vy[k] = b[k]; vd[k] = d[k]; }
+    } else {
+        vx[0] = x[i]; vy[0] = y[i]; vd[0] = dy[i];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float g = vd[k];
+        if (relu && !(vy[k] > 0.f)) g = 0.f;
+        float is = invstd[col + k];
+        float xh = (vx[k] - mean[col + k]) * is;
+        o[k] = gamma[col + k] * is * (g - coef[col + k] - xh * coef[c + col + k]);
+    }
+    if (VEC == 4) {
+        f32x4 t;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) t[k] = o[k];
+        *(f32x4 *)(dx + i) = t;
+    } else {
+        dx[i] = o[0];
+    }
 }
 
-static int bn_grid(int64_t n, long *rows_per_block)
+// rows handled by one block of the partial pass, and the number of blocks
+static int bn_grid(int64_t n, int c, int vec, long *rows_per_block)
 {
-    int nblk = (int)((n + 255) / 256);
-    if (nblk > BN_MAXBLK) nblk = BN_MAXBLK;
+    int R = 256 / (c / vec);
+    if (R < 1) R = 1;
+    long rpb = (long)R * 8;                       // at least 8 rows per lane
+    long need = (n + BN_MAXBLK - 1) / BN_MAXBLK;  // cap the block count
+    if (rpb < need) rpb = ((need + R - 1) / R) * R;
+    int nblk = (int)((n + rpb - 1) / rpb);
     if (nblk < 1) nblk = 1;
-    *rows_per_block = (long)((n + nblk - 1) / nblk);
+    *rows_per_block = rpb;
     return nblk;
 }
 
-extern "C" int urn_bn_relu_fwd(const float *x, int64_t n, int c, const float *gamma, const float *beta,
-                               double eps, int relu, float *y, float *mean, float *invstd,
-                               float *running_mean, float *running_var, double momentum, void *scratch,
-                               void *stream)
-{
-    URN_CHECK_ARG(c > 0 && n >= 0 && gamma && beta && mean && invstd && scratch, "bad argument");
-    URN_CHECK_ARG(n == 0 || (x && y), "null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    double *part = (double *)scratch;
-    long rpb;
-    int nblk = bn_grid(n, &rpb);
-    hipLaunchKernelGGL(k_bn_partial<0>, dim3(nblk, urn_cdiv(c, 256)), dim3(256), 0, st, x, (const float *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (long)n, c, 0, rpb,
-                       part);
-    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(urn_cdiv(c, 64)), dim3(64), 0, st, part, nblk, (long)n, c, eps, mean,
-                       invstd, running_mean, running_var, momentum);
-    long total = (long)n * c;
-    if (total > 0) {
-        if (c % 4 == 0)
-            hipLaunchKernelGGL(k_bn_apply_fwd, dim3(urn_cdiv(total / 4, 256)), dim3(256), 0, st, x, total, c, gamma,
-                               beta, mean, invstd, relu, y);
-        else
-            hipLaunchKernelGGL(k_bn_apply_fwd_scalar, dim3(urn_cdiv(total, 256)), dim3(256), 0, st, x, total, c,
-                               gamma, beta, mean, invstd, relu, y);
-    }
-    URN_LAUNCH_CHECK();
-    return URN_OK;
-}
+static inline int bn_vec(int c) { return (c % 4 == 0 && c / 4 <= 256) ? 4 : 1; }
+
+#define URN_BN_SHAPE_OK(c) (bn_vec(c) == 4 || (c) <= 256)
 
 extern "C" int urn_bn_relu_apply(const float *x, int64_t n, int c, const float *gamma, const float *beta,
                                  const float *mean, const float *invstd, int relu, float *y, void *stream)
@@ -148,44 +233,40 @@ extern "C" int urn_bn_relu_apply(const float *x, int64_t n, int c, const float *
     URN_CHECK_ARG(x && y, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (c % 4 == 0)
-        hipLaunchKernelGGL(k_bn_apply_fwd, dim3(urn_cdiv(total / 4, 256)), dim3(256), 0, st, x, total, c, gamma, beta,
-                           mean, invstd, relu, y);
-    else
-        hipLaunchKernelGGL(k_bn_apply_fwd_scalar, dim3(urn_cdiv(total, 256)), dim3(256), 0, st, x, total, c, gamma,
+        hipLaunchKernelGGL(k_bn_apply_fwd<4>, dim3(urn_cdiv(total / 4, 256)), dim3(256), 0, st, x, total, c, gamma,
                            beta, mean, invstd, relu, y);
+    else
+        hipLaunchKernelGGL(k_bn_apply_fwd<1>, dim3(urn_cdiv(total, 256)), dim3(256), 0, st, x, total, c, gamma, beta,
+                           mean, invstd, relu, y);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
 
-__global__ void k_bn_finalize_bwd(const double *__restrict__ part, int nblk, long n, int c,
-                                  float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                  float *__restrict__ coef /* [2][c]: sb/n, sg/n */)
+extern "C" int urn_bn_relu_fwd(const float *x, int64_t n, int c, const float *gamma, const float *beta,
+                               double eps, int relu, float *y, float *mean, float *invstd,
+                               float *running_mean, float *running_var, double momentum, void *scratch,
+                               void *stream)
 {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c) return;
-    double sb = 0.0, sg = 0.0;
-    for (int b = 0; b < nblk; ++b) { sb += part[((long)b * 2) * c + col]; sg += part[((long)b * 2 + 1) * c + col]; }
-    dbeta[col] = (float)sb;
-    dgamma[col] = (float)sg;
-    double invn = n > 0 ? 1.0 / (double)n : 0.0;
-    coef[col] = (float)(sb * invn);
-    coef[c + col] = (float)(sg * invn);
-}
-
-__global__ void k_bn_apply_bwd(const float *__restrict__ x, const float *__restrict__ y,
-                               const float *__restrict__ dy, long total, int c,
-                               const float *__restrict__ gamma, const float *__restrict__ mean,
-                               const float *__restrict__ invstd, const float *__restrict__ coef, int relu,
-                               float *__restrict__ dx)
-{
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int col = (int)(i % c);
-    float g = dy[i];
-    if (relu && !(y[i] > 0.f)) g = 0.f;
-    float is = invstd[col];
-    float xh = (x[i] - mean[col]) * is;
-    dx[i] = gamma[col] * is * (g - coef[col] - xh * coef[c + col]);
+    URN_CHECK_ARG(c > 0 && n >= 0 && gamma && beta && mean && invstd && scratch, "bad argument");
+    URN_CHECK_ARG(n == 0 || (x && y), "null pointer");
+    if (!URN_BN_SHAPE_OK(c)) { urn_set_error("urn_bn_relu_fwd: unsupported channel count %d", c); return URN_EUNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    double *part = (double *)scratch;
+    const int vec = bn_vec(c);
+    long rpb;
+    int nblk = bn_grid(n, c, vec, &rpb);
+    if (vec == 4)
+        hipLaunchKernelGGL((k_bn_partial<0, 4>), dim3(nblk), dim3(256), 0, st, x, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (long)n, c, 0, rpb,
+                           part);
+    else
+        hipLaunchKernelGGL((k_bn_partial<0, 1>), dim3(nblk), dim3(256), 0, st, x, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (long)n, c, 0, rpb,
+                           part);
+    hipLaunchKernelGGL(k_bn_finalize<0>, dim3(urn_cdiv(c, 16)), dim3(256), 0, st, part, nblk, (long)n, c, eps, mean,
+                       invstd, running_mean, running_var, momentum);
+    URN_LAUNCH_CHECK();
+    return urn_bn_relu_apply(x, n, c, gamma, beta, mean, invstd, relu, y, stream);
 }
 
 extern "C" int urn_bn_relu_bwd(const float *x, const float *y, const float *dy, int64_t n, int c,
@@ -194,22 +275,30 @@ extern "C" int urn_bn_relu_bwd(const float *x, const float *y, const float *dy, 
 {
     URN_CHECK_ARG(c > 0 && n >= 0 && gamma && mean && invstd && dgamma && dbeta && scratch, "bad argument");
     URN_CHECK_ARG(n == 0 || (x && y && dy && dx), "null pointer");
+    if (!URN_BN_SHAPE_OK(c)) { urn_set_error("urn_bn_relu_bwd: unsupported channel count %d", c); return URN_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     double *part = (double *)scratch;
-    // coefficients live after the partials (scratch has 256 spare bytes only for alignment, so
-    // carve them from the partial area's tail: nblk <= BN_MAXBLK-1 keeps one slab free)
+    float *coef = (float *)(part + (long)BN_MAXBLK * 2 * c);  // the slab after the partials
+    const int vec = bn_vec(c);
     long rpb;
-    int nblk = bn_grid(n, &rpb);
-    if (nblk == BN_MAXBLK) { nblk = BN_MAXBLK - 1; rpb = (long)((n + nblk - 1) / nblk); }
-    float *coef = (float *)(part + (long)(BN_MAXBLK - 1) * 2 * c);
-    hipLaunchKernelGGL(k_bn_partial<1>, dim3(nblk, urn_cdiv(c, 256)), dim3(256), 0, st, x, y, dy, mean, invstd,
-                       (long)n, c, relu, rpb, part);
-    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(urn_cdiv(c, 64)), dim3(64), 0, st, part, nblk, (long)n, c, dgamma,
-                       dbeta, coef);
+    int nblk = bn_grid(n, c, vec, &rpb);
+    if (vec == 4)
+        hipLaunchKernelGGL((k_bn_partial<1, 4>), dim3(nblk), dim3(256), 0, st, x, y, dy, mean, invstd, (long)n, c, relu,
+                           rpb, part);
+    else
+        hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3(nblk), dim3(256), 0, st, x, y, dy, mean, invstd, (long)n, c, relu,
+                           rpb, part);
+    hipLaunchKernelGGL(k_bn_finalize<1>, dim3(urn_cdiv(c, 16)), dim3(256), 0, st, part, nblk, (long)n, c, 0.0, dgamma,
+                       dbeta, coef, coef + c, 0.0);
     long total = (long)n * c;
-    if (total > 0)
-        hipLaunchKernelGGL(k_bn_apply_bwd, dim3(urn_cdiv(total, 256)), dim3(256), 0, st, x, y, dy, total, c, gamma,
-                           mean, invstd, coef, relu, dx);
+    if (total > 0) {
+        if (c % 4 == 0)
+            hipLaunchKernelGGL(k_bn_apply_bwd<4>, dim3(urn_cdiv(total / 4, 256)), dim3(256), 0, st, x, y, dy, total, c,
+                               gamma, mean, invstd, coef, relu, dx);
+        else
+            hipLaunchKernelGGL(k_bn_apply_bwd<1>, dim3(urn_cdiv(total, 256)), dim3(256), 0, st, x, y, dy, total, c,
+                               gamma, mean, invstd, coef, relu, dx);
+    }
     URN_LAUNCH_CHECK();
     return URN_OK;
 }

@@ -15,142 +15,9 @@
 //   pairs of an offset are compacted with wave64 ballot/popcount prefix sums, staged
 //   through LDS in batches of 32 pairs and contracted with the same MFMA.
 #include "urn_common.h"
+#include "urn_prof.h"
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-// ------------------------------------------------------------------ forward / dX --
-template <int MB, int NB>
-__global__ __launch_bounds__(256) void k_gconv_fwd(const float *__restrict__ x, const float *__restrict__ wt,
-                                                   const int *__restrict__ tbl, long ld, int K, int flip,
-                                                   long n_out, int cin, int cout,
-                                                   const float *__restrict__ res, float *__restrict__ y)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const long row_base = ((long)blockIdx.x * 4 + wave) * (MB * 16);
-    if (row_base >= n_out) return;  // wave-uniform
-    const int col_base = blockIdx.y * (NB * 16);
-
-    f32x4 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int o = 0; o < K; ++o) {
-        const int to = flip ? (K - 1 - o) : o;
-        int idx[MB];
-        bool act[MB];
-        bool any = false;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            long row = row_base + mb * 16 + r;
-            idx[mb] = (row < n_out) ? tbl[(long)to * ld + row] : -1;
-            act[mb] = __ballot(idx[mb] >= 0) != 0ull;
-            any |= act[mb];
-        }
-        if (!any) continue;  // wave-uniform
-        const float *wo = wt + (long)o * cout * cin + (long)(col_base + r) * cin + 4 * q;
-        for (int k0 = 0; k0 < cin; k0 += 16) {
-            f32x4 a[MB], b[NB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                a[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (idx[mb] >= 0) a[mb] = *(const f32x4 *)(x + (long)idx[mb] * cin + k0 + 4 * q);
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4 *)(wo + (long)nb * 16 * cin + k0);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                if (!act[mb]) continue;  // wave-uniform
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = MFMA16(a[mb][t], b[nb][t], acc[mb][nb]);
-            }
-        }
-    }
-    // C layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            long row = row_base + mb * 16 + q * 4 + i;
-            if (row >= n_out) continue;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                long off = row * cout + col_base + nb * 16 + r;
-                float v = acc[mb][nb][i];
-                if (res) v += res[off];
-                y[off] = v;
-            }
-        }
-}
-
-// VALU fallback for widths that are not multiples of 16 (the 1-channel stem).
-__global__ void k_gconv_small(const float *__restrict__ x, const float *__restrict__ wt,
-                              const int *__restrict__ tbl, long ld, int K, int flip, long n_out, int cin,
-                              int cout, const float *__restrict__ res, float *__restrict__ y)
-{
-    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_out * cout) return;
-    long j = t / cout;
-    int c = (int)(t - j * cout);
-    float acc = 0.f;
-    for (int o = 0; o < K; ++o) {
-        int to = flip ? (K - 1 - o) : o;
-        int i = tbl[(long)to * ld + j];
-        if (i < 0) continue;
-        const float *xi = x + (long)i * cin;
-        const float *w = wt + ((long)o * cout + c) * cin;
-        for (int a = 0; a < cin; ++a) acc = fmaf(xi[a], w[a], acc);
-    }
-    if (res) acc += res[t];
-    y[t] = acc;
-}
-
-template <int MB, int NB>
-static void launch_fwd(const float *x, const float *wt, const int *tbl, long ld, int K, int flip, long n_out,
-                       int cin, int cout, const float *res, float *y, hipStream_t st)
-{
-    dim3 grid(urn_cdiv(n_out, 4 * MB * 16), cout / (NB * 16));
-    hipLaunchKernelGGL((k_gconv_fwd<MB, NB>), grid, dim3(256), 0, st, x, wt, tbl, ld, K, flip, n_out, cin, cout,
-                       res, y);
-}
-
-extern "C" int urn_gconv_fwd(const float *x, const float *wt, const int32_t *tbl, int64_t ld, int K, int flip,
-                             int64_t n_out, int cin, int cout, const float *res, float *y, void *stream)
-{
-    if (n_out <= 0) return URN_OK;
-    URN_CHECK_ARG(x && wt && tbl && y, "null pointer");
-    URN_CHECK_ARG(K > 0 && cin > 0 && cout > 0 && ld >= n_out, "bad shape");
-    URN_CHECK_ARG((const void *)x != (const void *)y, "y aliases x");
-    hipStream_t st = (hipStream_t)stream;
-    if ((cin % 16) || (cout % 16)) {
-        hipLaunchKernelGGL(k_gconv_small, dim3(urn_cdiv(n_out * cout, 256)), dim3(256), 0, st, x, wt, tbl, (long)ld,
-                           K, flip, (long)n_out, cin, cout, res, y);
-        URN_LAUNCH_CHECK();
-        return URN_OK;
-    }
-    const int nblk = cout / 16;
-    // columns per wave: the largest divisor of cout/16 that is <= 5
-    int nb = 1;
-    for (int d = 5; d >= 1; --d)
-        if (nblk % d == 0) { nb = d; break; }
-    // rows per wave: 32 when that still fills the chip, else 16
-    const bool big = (n_out / 128) * (nblk / nb) >= 512;
-#define URN_FWD(MBv, NBv) launch_fwd<MBv, NBv>(x, wt, tbl, ld, K, flip, n_out, cin, cout, res, y, st)
-    switch (nb) {
-    case 1: big ? URN_FWD(2, 1) : URN_FWD(1, 1); break;
-    case 2: big ? URN_FWD(2, 2) : URN_FWD(1, 2); break;
-    case 3: big ? URN_FWD(2, 3) : URN_FWD(1, 3); break;
-    case 4: big ? URN_FWD(2, 4) : URN_FWD(1, 4); break;
-    default: big ? URN_FWD(2, 5) : URN_FWD(1, 5); break;
-    }
-#undef URN_FWD
-    URN_LAUNCH_CHECK();
-    return URN_OK;
-}
 
 // ---------------------------------------------------------------- weight gradient --
 // grid (row chunks, K, output tiles); block 256 = 4 waves.
@@ -305,15 +172,18 @@ extern "C" int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *
         return URN_OK;
     }
     const int n_ci_tiles = urn_cdiv(cin, DW_MAXI * 16), n_co_tiles = urn_cdiv(cout, DW_MAXN * 16);
-    // aim for ~1024 blocks, chunks of at least 512 rows (multiple of 256)
-    int chunks = 1024 / (K * n_ci_tiles * n_co_tiles);
+    // aim for ~2048 blocks, chunks of at least 256 rows (multiple of 256)
+    int chunks = 2048 / (K * n_ci_tiles * n_co_tiles);
     if (chunks < 1) chunks = 1;
     long chunk = (n_out + chunks - 1) / chunks;
-    if (chunk < 512) chunk = 512;
+    if (chunk < 256) chunk = 256;
     chunk = ((chunk + 255) / 256) * 256;
     chunks = (int)((n_out + chunk - 1) / chunk);
+    const bool prof = urn_prof_on();
+    if (prof) urn_prof_begin(URN_PROF_DW, st);
     hipLaunchKernelGGL(k_gconv_dw, dim3(chunks, K, n_ci_tiles * n_co_tiles), dim3(256), 0, st, x, dy, tbl, (long)ld,
                        (long)n_out, cin, cout, chunk, n_ci_tiles, dw);
+    if (prof) urn_prof_end(st);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }

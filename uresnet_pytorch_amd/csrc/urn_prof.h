@@ -1,0 +1,8 @@
+#pragma once
+#include <hip/hip_runtime.h>
+// kernel classes for urn_prof_read()
+#define URN_PROF_GCONV 0   /* k_gconv_fwd<MB,NB>: forward and input-gradient gather conv */
+#define URN_PROF_DW 1      /* k_gconv_dw: weight gradient */
+bool urn_prof_on();
+void urn_prof_begin(int kind, hipStream_t st);
+void urn_prof_end(hipStream_t st);

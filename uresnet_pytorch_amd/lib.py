@@ -46,6 +46,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'urn_rows_scatter_add': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    'urn_prof_enable': (c_int, [c_int]),
+    'urn_prof_read': (c_int, [c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_i64)]),
 }
 
 

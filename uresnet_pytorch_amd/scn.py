@@ -51,12 +51,25 @@ class Identity(nn.Module):
 
 
 class ConcatTable(nn.Module):
+    """fuse_add: the table feeds an AddTable and its last branch ends in a
+    SubmanifoldConvolution -- the shortcut is then added in that kernel's epilogue."""
+    fuse_add = False
+
     def add(self, module):
         self.add_module(str(len(self._modules)), module)
         return self
 
     def forward(self, x):
-        return [m(x) for m in self._modules.values()]
+        mods = list(self._modules.values())
+        if self.fuse_add and len(mods) == 2 and isinstance(mods[1], Sequential):
+            tail = list(mods[1]._modules.values())
+            if isinstance(tail[-1], SubmanifoldConvolution):
+                shortcut = mods[0](x)
+                t = x
+                for m in tail[:-1]:
+                    t = m(t)
+                return [tail[-1](t, res=shortcut.features)]
+        return [m(x) for m in mods]
 
 
 class AddTable(nn.Module):
@@ -206,14 +219,15 @@ def UNet(dimension, reps, nPlanes, residual_blocks=False, downsample=(2, 2), lea
         raise ValueError('only residual_blocks=True (the reference configuration) is supported')
 
     def block(m, a, b):
-        m.add(ConcatTable()
-              .add(Identity() if a == b else NetworkInNetwork(a, b, False))
-              .add(Sequential()
-                   .add(BatchNormLeakyReLU(a, leakiness=leakiness))
-                   .add(SubmanifoldConvolution(dimension, a, b, 3, False))
-                   .add(BatchNormLeakyReLU(b, leakiness=leakiness))
-                   .add(SubmanifoldConvolution(dimension, b, b, 3, False)))
-              ).add(AddTable())
+        table = (ConcatTable()
+                 .add(Identity() if a == b else NetworkInNetwork(a, b, False))
+                 .add(Sequential()
+                      .add(BatchNormLeakyReLU(a, leakiness=leakiness))
+                      .add(SubmanifoldConvolution(dimension, a, b, 3, False))
+                      .add(BatchNormLeakyReLU(b, leakiness=leakiness))
+                      .add(SubmanifoldConvolution(dimension, b, b, 3, False))))
+        table.fuse_add = True
+        m.add(table).add(AddTable())
 
     def U(planes):
         m = Sequential()

@@ -71,14 +71,20 @@ class SparseGeometry:
                 self.chd.append(chd); self.up.append(up)
             nbr = self._nbr_all[l]
             _l.check(L.urn_rulebook_subm(self.coords[l].data_ptr(), n_dev, cap, sp, self._hptr[l], hcap,
-                                         nbr.data_ptr(), cap, cptr + 4 * (self.num_levels + l), st),
-                     'rulebook_subm')
+                                         nbr.data_ptr(), cap, None, st), 'rulebook_subm')
             self.nbr.append(nbr)
             sp = (sp + 1) // 2
         self._scratch = scratch
         host = self.counts.cpu().tolist()       # the one sync of the integer phase
         self.n = host[:self.num_levels]
-        self.rules = host[self.num_levels:]
+        self._rules = None
+
+    @property
+    def rules(self):
+        """Number of (offset, in, out) rules per level (only measurement and tests need it)."""
+        if self._rules is None:
+            self._rules = [int((self.nbr[l][:, :self.n[l]] >= 0).sum().item()) for l in range(self.num_levels)]
+        return self._rules
 
     # canonical exports for parity tests (device -> host)
     def export_nbr(self, level):
