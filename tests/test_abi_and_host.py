@@ -1,0 +1,127 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/uresnet_hip.h declares,
+host logic (event sharding, flat gradients, flags, io blobs, checkpoints)."""
+import ctypes
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from uresnet_pytorch_amd import lib
+    L = lib.load()
+    hdr = open(os.path.join(ROOT, 'include', 'uresnet_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)          # prose in comments is not a declaration
+    declared = set(re.findall(r'\b(urn_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations found'
+    for name in declared:
+        assert hasattr(L, name), 'symbol %s declared in the header but not exported' % name
+    assert declared == set(lib.SIGNATURES.keys()), declared ^ set(lib.SIGNATURES.keys())
+    assert L.urn_version() >= 100
+    # pure-host helpers can be called without a GPU
+    assert L.urn_hash_capacity(50000) == 131072 and L.urn_hash_bytes(1024) == 16384
+    assert L.urn_unique_scratch_bytes(1000) > 4000 and L.urn_bn_scratch_bytes(16) > 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    from uresnet_pytorch_amd.models import SparseUResNet
+    fl = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=2, SPATIAL_SIZE=16, NUM_CLASS=3)
+    net = SparseUResNet(fl)
+    pc = torch.tensor([[1., 2., 3., 0., 0.5], [1., 2., 4., 0., 0.7]])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net(pc)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'uresnet_pytorch_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_shard_events_balanced_and_deterministic():
+    from uresnet_pytorch_amd.parallel import shard_events
+    sizes = [50000, 10000, 42000, 38000, 7000, 51000, 20000, 30000]
+    out = shard_events(sizes, 4)
+    assert sorted(sum(out, [])) == list(range(8))
+    loads = [sum(sizes[i] for i in r) for r in out]
+    assert max(loads) - min(loads) <= max(sizes) * 0.5
+    assert out == shard_events(sizes, 4)
+    assert shard_events([5, 4, 3], 1) == [[0, 1, 2]]
+    assert shard_events([], 2) == [[], []]
+
+
+def test_flat_gradients_views():
+    from uresnet_pytorch_amd.parallel import FlatGradients
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    fg = FlatGradients(m)
+    assert fg.flat.numel() == sum(p.numel() for p in m.parameters())
+    m(torch.randn(5, 4)).sum().backward()
+    assert fg.flat.abs().sum() > 0
+    assert all(p.grad.data_ptr() >= fg.flat.data_ptr() for p in m.parameters())   # still views after backward
+    g0 = fg.flat.clone()
+    m(torch.randn(5, 4)).sum().backward()      # accumulates in place
+    assert not torch.equal(g0, fg.flat)
+    fg.zero()
+    assert fg.flat.abs().sum() == 0 and all(p.grad.abs().sum() == 0 for p in m.parameters())
+
+
+def test_flags_names_and_batch_rules(monkeypatch):
+    from uresnet_pytorch_amd.flags import URESNET_FLAGS
+    fl = URESNET_FLAGS().parse_args(['train', '-mn', 'uresnet_sparse', '-io', 'synthetic_sparse', '-ss', '512',
+                                     '-uf', '16', '-uns', '5', '-nc', '5', '-bs', '16', '--gpus', '0,1',
+                                     '-dkeys', 'data,label', '-sd', '7', '-lr', '0.01'], run=False)
+    assert fl.MODEL_NAME == 'uresnet_sparse' and fl.SPATIAL_SIZE == 512 and fl.URESNET_FILTERS == 16
+    assert fl.URESNET_NUM_STRIDES == 5 and fl.NUM_CLASS == 5 and fl.GPUS == [0, 1]
+    assert fl.BATCH_SIZE == 16 and fl.MINIBATCH_SIZE == 8 and fl.SEED == 7 and fl.LEARNING_RATE == 0.01
+    assert fl.DATA_KEYS == ['data', 'label'] and fl.DATA_DIM == 3
+    with pytest.raises(ValueError):
+        URESNET_FLAGS().parse_args(['train', '-mn', 'x'], run=False)               # both batch sizes negative
+    with pytest.raises(ValueError):
+        URESNET_FLAGS().parse_args(['train', '-bs', '3', '-mbs', '2'], run=False)   # not a multiple
+
+
+def test_sparse_blob_layout():
+    from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
+    b = make_sparse_blob([3, 4], 64, 500, compute_weight=True)
+    d = b['data']
+    assert d.shape == (1000, 5) and d.dtype == np.float32
+    assert set(np.unique(d[:, 3])) == {0.0, 1.0} and (d[:, 4] > 0).all()
+    assert d[:, :3].min() >= 0 and d[:, :3].max() <= 63
+    assert len(np.unique(d[:500, :3], axis=0)) == 500          # unique voxels per event
+    assert b['label'].shape == (1000, 1) and b['weight'].shape == (1000, 1)
+    b2 = make_sparse_blob([3, 4], 64, 500)
+    assert np.array_equal(b2['data'], d)                        # deterministic
+
+
+def test_trainer_checkpoint_roundtrip_dense_cpu(tmp_path):
+    """reference trainval.py:32-40,171-196: {'global_step','state_dict','optimizer'}, resume at step+1."""
+    from uresnet_pytorch_amd.trainval import trainval
+    from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+
+    def flags(path=''):
+        return SimpleNamespace(MODEL_NAME='uresnet_dense', DATA_DIM=2, URESNET_FILTERS=4, URESNET_NUM_STRIDES=2,
+                               SPATIAL_SIZE=16, NUM_CLASS=3, BN_MOMENTUM=0.9, TRAIN=True, GPUS=[],
+                               LEARNING_RATE=1e-3, MODEL_PATH=path, WEIGHT_PREFIX=str(tmp_path / 'snap'))
+    b = make_dense_blob([0, 1], 16, 2, 3)
+    blob = {'data': [[b['data'][0], b['data'][1]]], 'label': [[b['label'][0], b['label'][1]]]}
+    torch.manual_seed(0)
+    t = trainval(flags())
+    assert t.initialize() == 0
+    res = t.train_step(blob, epoch=0., batch_size=2)
+    assert set(res.keys()) == {'segmentation', 'softmax', 'accuracy', 'loss_seg'}
+    assert res['segmentation'][0].shape == (3, 16, 16) and abs(res['softmax'][0].sum(0) - 1).max() < 1e-5
+    assert t.tspent['train'] > 0 and t.tspent_sum['forward'] > 0
+    t.save_state(4)
+    t2 = trainval(flags(str(tmp_path / 'snap-4.ckpt')))
+    assert t2.initialize() == 5
+    for (k1, v1), (k2, v2) in zip(t._net.state_dict().items(), t2._net.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)

@@ -1,0 +1,59 @@
+"""The py3 dense model (CPU route) against golden vectors generated from the REFERENCE dense
+model (tools/make_golden.py; reference uresnet/models/uresnet_dense.py imported in the build
+container).  fp32, tolerance 1e-5 relative."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from uresnet_pytorch_amd.models import DenseUResNet, DenseSegmentationLoss
+from uresnet_pytorch_amd.models.uresnet_dense import padding
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def load(name, device='cpu'):
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    dim, ss, uf, uns, nc, B = [int(v) for v in g['flags']]
+    flags = SimpleNamespace(DATA_DIM=dim, URESNET_FILTERS=uf, URESNET_NUM_STRIDES=uns, SPATIAL_SIZE=ss,
+                            NUM_CLASS=nc, BN_MOMENTUM=0.9)
+    net = DenseUResNet(flags)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    assert set(sd.keys()) == set(net.state_dict().keys())      # same state_dict keys as the reference
+    net.load_state_dict(sd)
+    return g, flags, net.to(device).train()
+
+
+@pytest.mark.parametrize('name', ['dense_cfg1_2d', 'dense_mini_3d'])
+def test_dense_model_matches_reference_golden(name):
+    g, flags, net = load(name)
+    x = torch.from_numpy(g['input']); lab = torch.from_numpy(g['label']); w = torch.from_numpy(g['weight'])
+    logits = net(x)
+    assert rel(logits.detach().numpy(), g['logits']) < TOL
+    crit = DenseSegmentationLoss(flags)
+    loss, acc = crit(list(logits), list(x), list(lab), None)
+    assert abs(loss.item() - float(g['loss'])) < TOL * abs(float(g['loss']))
+    assert abs(acc - float(g['acc'])) < 1e-6
+    loss.backward()
+    have = sorted(k for k, p in net.named_parameters() if p.grad is not None)
+    assert have == list(g['grad_keys_with_grad'])              # unused shortcut convs get no grad
+    for k in g.files:
+        if k.startswith('grad/'):
+            p = dict(net.named_parameters())[k[5:]]
+            assert rel(p.grad.numpy(), g[k]) < 20 * TOL, k     # grads through ~30 BN layers
+    loss_w, acc_w = crit(list(net(x)), list(x), list(lab), list(w))
+    assert abs(loss_w.item() - float(g['loss_w'])) < TOL * abs(float(g['loss_w']))
+
+
+def test_padding_table_matches_reference():
+    g = np.load(os.path.join(GOLD, 'dense_cfg1_2d.npz'))
+    for k, s, n, p1, p2, p3, p4 in g['padding_table']:
+        assert padding(int(k), int(s), (1, 1, int(n), int(n))) == (p1, p2, p3, p4)

@@ -205,10 +205,12 @@ extern "C" int urn_gconv_fwd(const float *x, const float *wt, const int32_t *tbl
     const int nblk = cout / 16;
     // columns per wave: the largest divisor of cout/16 that keeps the operand registers under budget
     const int nb_max = ks <= 5 ? 5 : (ks <= 8 ? 4 : 2);
+    const bool split = K >= 8;
+    // ... and that still leaves >= ~4 waves per SIMD (1024 SIMDs) to hide the gather latency
+    const long tiles16 = (n_out + 15) / 16;
     int nb = 1;
     for (int d = nb_max; d >= 1; --d)
-        if (nblk % d == 0) { nb = d; break; }
-    const bool split = K >= 8;
+        if (nblk % d == 0 && (d == 1 || tiles16 * (split ? 4 : 1) * (nblk / d) >= 4096)) { nb = d; break; }
     FwdArgs a{x, wt, tbl, (long)ld, K, flip, (long)n_out, cout, res, y, st};
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_GCONV, st);

@@ -1,0 +1,175 @@
+"""Trainer with the reference's API (reference uresnet/trainval.py:15-198):
+trainval(flags).initialize() / train_step(data_blob, epoch, batch_size) / forward(...) /
+save_state(iteration), timing dicts tspent / tspent_sum, result keys
+segmentation / softmax / accuracy / loss_seg.
+
+Differences, all on purpose:
+  * one process per GPU instead of single-process DataParallel: each rank runs the events
+    of data_blob[...][substep][local gpu slot]; gradients are summed over ranks with ONE
+    RCCL all-reduce of a flat buffer (uresnet_pytorch_amd.parallel);
+  * tensors stay batched without a GPU (the reference's no-CUDA branch drops the batch
+    dimension, trainval.py:95-102) -- only the dense model can run on CPU, the sparse HIP
+    path raises without a GPU;
+  * logits/softmax are moved to the host once per forward, as the reference does (:127-128).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import models
+from . import parallel
+
+
+class trainval(object):
+    def __init__(self, flags):
+        self._flags = flags
+        self.tspent = {}
+        self.tspent_sum = {}
+
+    # -- reference trainval.py:21-30
+    def backward(self):
+        total_loss = 0.0
+        for loss in self._loss:
+            total_loss = total_loss + loss
+        total_loss = total_loss / len(self._loss)
+        self._loss = []
+        self._grads.zero()
+        total_loss.backward()
+        self._grads.all_reduce()          # SUM over ranks: the reference loss is a sum over all events
+        self._optimizer.step()
+
+    # -- reference trainval.py:32-40
+    def save_state(self, iteration):
+        tstart = time.time()
+        filename = '%s-%d.ckpt' % (self._flags.WEIGHT_PREFIX, iteration)
+        if self._rank == 0:
+            torch.save({
+                'global_step': iteration,
+                'state_dict': self._net.state_dict(),
+                'optimizer': self._optimizer.state_dict()
+            }, filename)
+        self.tspent['save'] = time.time() - tstart
+
+    # -- reference trainval.py:42-51
+    def train_step(self, data_blob, epoch=None, batch_size=1):
+        tstart = time.time()
+        self._loss = []
+        res_combined = self.forward(data_blob, epoch=epoch, batch_size=batch_size)
+        self.backward()
+        self.tspent['train'] = time.time() - tstart
+        self.tspent_sum['train'] += self.tspent['train']
+        return res_combined
+
+    # -- reference trainval.py:53-73
+    def forward(self, data_blob, epoch=None, batch_size=1):
+        res_combined = {}
+        for idx in range(len(data_blob['data'])):
+            blob = {}
+            for key in data_blob.keys():
+                blob[key] = data_blob[key][idx]
+            res = self._forward(blob, epoch=epoch)
+            for key in res.keys():
+                if key not in res_combined:
+                    res_combined[key] = res[key]
+                else:
+                    res_combined[key].extend(res[key])
+        acc = float(np.array(res_combined['accuracy']).sum())
+        loss = float(np.array(res_combined['loss_seg']).sum())
+        acc, loss = parallel.all_reduce_scalars([acc, loss], self._device)
+        res_combined['accuracy'] = acc / batch_size
+        res_combined['loss_seg'] = loss / batch_size
+        return res_combined
+
+    def _local_slots(self, n):
+        """Entries of a per-GPU list that this rank owns (contiguous chunks, like the reference's
+        scatter, reference uresnet/ops.py:28-36)."""
+        per = max(1, n // self._world)
+        return list(range(self._rank * per, min(n, (self._rank + 1) * per))) if self._world > 1 else list(range(n))
+
+    # -- reference trainval.py:75-134
+    def _forward(self, data_blob, epoch=None):
+        data = data_blob['data']
+        label = data_blob.get('label', None)
+        weight = data_blob.get('weight', None)
+        slots = self._local_slots(len(data))
+        sparse = 'sparse' in self._flags.MODEL_NAME
+        with torch.set_grad_enabled(self._flags.TRAIN):
+            data = [torch.as_tensor(data[i]).to(self._device) for i in slots]
+            tstart = time.time()
+            if sparse:
+                segmentation = []
+                for d in data:
+                    segmentation.extend(self._net(d))
+            else:
+                segmentation = list(self._net(torch.stack(data)))
+            loss_seg, acc = 0., 0.
+            if label is not None:
+                label = [torch.as_tensor(label[i]).to(self._device) for i in slots]
+                if weight is not None:
+                    weight = [torch.as_tensor(weight[i]).to(self._device) for i in slots]
+                loss_seg, acc = self._criterion(segmentation, data, label, weight)
+                if self._flags.TRAIN:
+                    self._loss.append(loss_seg)
+            res = {
+                'segmentation': [s.detach().cpu().numpy() for s in segmentation],
+                'softmax': [self._softmax(s).detach().cpu().numpy() for s in segmentation],
+                'accuracy': [acc],
+                'loss_seg': [loss_seg.item() if not isinstance(loss_seg, float) else loss_seg]
+            }
+            self.tspent['forward'] = time.time() - tstart
+            self.tspent_sum['forward'] += self.tspent['forward']
+            return res
+
+    # -- reference trainval.py:136-198
+    def initialize(self):
+        model = None
+        if self._flags.MODEL_NAME == 'uresnet_sparse':
+            model = models.SparseUResNet
+            self._criterion = models.SparseSegmentationLoss(self._flags)
+        elif self._flags.MODEL_NAME == 'uresnet_dense':
+            model = models.DenseUResNet
+            self._criterion = models.DenseSegmentationLoss(self._flags)
+        else:
+            raise Exception("Unknown model name provided")
+
+        self.tspent_sum['forward'] = self.tspent_sum['train'] = self.tspent_sum['save'] = 0.
+        self.tspent['forward'] = self.tspent['train'] = self.tspent['save'] = 0.
+
+        self._rank, self._world, local_rank = parallel.init_distributed()
+        use_gpu = torch.cuda.is_available() and len(getattr(self._flags, 'GPUS', [0])) > 0
+        self._device = torch.device('cuda', local_rank) if use_gpu else torch.device('cpu')
+        if use_gpu:
+            torch.cuda.set_device(self._device)
+        self._net = model(self._flags).to(self._device)
+        if self._flags.TRAIN:
+            self._net.train()
+        else:
+            self._net.eval()
+        self._criterion.to(self._device)
+
+        self._optimizer = torch.optim.Adam(self._net.parameters(), lr=self._flags.LEARNING_RATE)
+        self._softmax = torch.nn.Softmax(dim=1 if 'sparse' in self._flags.MODEL_NAME else 0)
+
+        iteration = 0
+        if self._flags.MODEL_PATH:
+            if not os.path.isfile(self._flags.MODEL_PATH):
+                sys.stderr.write('File not found: %s\n' % self._flags.MODEL_PATH)
+                raise ValueError
+            print('Restoring weights from %s...' % self._flags.MODEL_PATH)
+            with open(self._flags.MODEL_PATH, 'rb') as f:
+                checkpoint = torch.load(f, map_location=self._device, weights_only=True)
+            state = {(k[len('module.'):] if k.startswith('module.') else k): v
+                     for k, v in checkpoint['state_dict'].items()}     # DataParallel prefix (reference :181)
+            self._net.load_state_dict(state, strict=False)
+            if self._flags.TRAIN:
+                self._optimizer.load_state_dict(checkpoint['optimizer'])
+                for g in self._optimizer.param_groups:
+                    g['lr'] = self._flags.LEARNING_RATE
+            iteration = checkpoint['global_step'] + 1
+            print('Done.')
+        parallel.broadcast_parameters(self._net)
+        self._grads = parallel.FlatGradients(self._net)
+        return iteration
