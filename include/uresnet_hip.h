@@ -125,6 +125,29 @@ int urn_rows_gather(const float *x, const int32_t *idx, int64_t n, int c, float 
 int urn_rows_scatter_add(const float *dy, const int32_t *idx, int64_t n, int c, float *dx,
                          void *stream);
 
+/* ------------------------------------------------------------------ whole-network executor
+ * The trunk of the sparse model -- everything between scn.InputLayer and torch.nn.Linear at
+ * reference uresnet_sparse.py:19-25 -- run from C++: the same kernels as the per-layer entry
+ * points, issued back-to-back on `stream`, activations carved from ONE caller-provided workspace.
+ * Parameters (and gradients) are one flat fp32 buffer in module registration order; running BN
+ * statistics are one flat buffer ([mean(c) | var(c)] per BatchNorm, registration order).
+ * Geometry is handed over as plain arrays (per-level counts and table pointers, leading dim ld).
+ * urn_net_backward replays the LAST urn_net_forward of the same handle and needs the same
+ * workspace untouched; it ACCUMULATES into `grads` (caller zeroes). */
+typedef struct urn_net urn_net;
+int urn_net_create(int m, int num_levels, int reps, int num_class, double eps, double momentum, urn_net **out);
+void urn_net_destroy(urn_net *net);
+int64_t urn_net_param_count(const urn_net *net);
+int64_t urn_net_running_count(const urn_net *net);
+int urn_net_num_tensors(const urn_net *net);
+int urn_net_tensor(const urn_net *net, int i, int64_t *off, int64_t *numel);
+int64_t urn_net_workspace_bytes(urn_net *net, int num_levels, const int64_t *n, int64_t n_rows, int with_backward);
+int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const int64_t *n, const void *const *nbr,
+                    const void *const *chd, const void *const *up, const int32_t *row2site, int64_t n_rows,
+                    const float *params, float *running, const float *site_feats, void *ws, int64_t ws_bytes,
+                    float *out_rows, int training, void *stream);
+int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stream);
+
 /* ----------------------------------------------------------------------- measurement
  * Optional per-kernel timing (HIP events on the launch stream), off by default.
  * kind 0 = gather-conv forward/input-gradient kernel, 1 = weight-gradient kernel.

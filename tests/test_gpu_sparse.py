@@ -233,3 +233,52 @@ def test_network_cfg3_full_size(dev):
     blob = make_sparse_blob([0], 512, 50000)
     e_fwd, e_grad = run_network_parity(dev, 512, 16, 5, 5, blob['data'], blob['label'], TOL, 5e-3)
     print('cfg3 parity: logits rel err %.2e, worst grad rel err %.2e' % (e_fwd, e_grad))
+
+
+def test_executor_matches_per_layer_path(dev):
+    """The C++ whole-network executor and the per-layer autograd path issue the same kernels:
+    identical logits (bitwise), gradients equal up to the fp32 atomics order of the weight gradient."""
+    from uresnet_pytorch_amd.models import SparseSegmentationLoss
+    S, m, L, nc = 64, 16, 4, 5
+    blob = make_sparse_blob([5, 6], S, 3000)
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=L, SPATIAL_SIZE=S, NUM_CLASS=nc)
+    P = orc.init_params(m, L, nc, seed=2)
+    data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
+    outs, grads, runs = [], [], []
+    for use_ex in (True, False):
+        net = make_model(flags, P, dev)
+        net.use_executor = use_ex
+        out = net(data)
+        loss, _ = SparseSegmentationLoss(flags)(out, [data], [label], None)
+        loss.backward()
+        outs.append(out[0].detach().cpu().numpy())
+        grads.append({k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()})
+        runs.append({k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items() if 'running' in k})
+    assert np.array_equal(outs[0], outs[1])
+    for k in grads[0]:
+        assert rel(grads[0][k], grads[1][k]) < 1e-5, k
+    for k in runs[0]:
+        assert np.array_equal(runs[0][k], runs[1][k]), k      # running statistics updated identically
+
+
+def test_executor_two_forwards_before_backward(dev):
+    """Gradient accumulation over two events run as two forwards then one backward (trainval sub-steps):
+    each forward gets its own executor slot, so neither tape is overwritten."""
+    from uresnet_pytorch_amd.models import SparseSegmentationLoss
+    S, m, L, nc = 32, 16, 3, 5
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=L, SPATIAL_SIZE=S, NUM_CLASS=nc)
+    P = orc.init_params(m, L, nc, seed=3)
+    blobs = [make_sparse_blob([s], S, 700) for s in (1, 2)]
+    crit = SparseSegmentationLoss(flags)
+    res = []
+    for use_ex in (True, False):
+        net = make_model(flags, P, dev)
+        net.use_executor = use_ex
+        total = 0
+        for b in blobs:
+            d = torch.from_numpy(b['data']).to(dev); lab = torch.from_numpy(b['label']).to(dev)
+            total = total + crit(net(d), [d], [lab], None)[0]
+        total.backward()
+        res.append({k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()})
+    for k in res[0]:
+        assert rel(res[0][k], res[1][k]) < 1e-5, k

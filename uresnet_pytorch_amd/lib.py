@@ -46,6 +46,17 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'urn_rows_scatter_add': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    'urn_net_create': (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, ctypes.POINTER(c_void_p)]),
+    'urn_net_destroy': (None, [c_void_p]),
+    'urn_net_param_count': (c_i64, [c_void_p]),
+    'urn_net_running_count': (c_i64, [c_void_p]),
+    'urn_net_num_tensors': (c_int, [c_void_p]),
+    'urn_net_tensor': (c_int, [c_void_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    'urn_net_workspace_bytes': (c_i64, [c_void_p, c_int, ctypes.POINTER(c_i64), c_i64, c_int]),
+    'urn_net_forward': (c_int, [c_void_p, c_int, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_void_p),
+                                ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_i64, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
+    'urn_net_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_prof_enable': (c_int, [c_int]),
     'urn_prof_read': (c_int, [c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_i64)]),
 }

@@ -7,6 +7,8 @@ by uresnet_pytorch_amd.scn, i.e. hand-written gfx950 kernels behind the C ABI.
 import torch
 
 from .. import scn
+from .. import sparse_ops as so
+from ..trunk import TrunkExecutor
 
 
 class UResNet(torch.nn.Module):
@@ -27,12 +29,30 @@ class UResNet(torch.nn.Module):
             scn.OutputLayer(dimension))
         self.sparseModel[0].num_levels = len(nPlanes)   # build every strided level in one integer phase
         self.linear = torch.nn.Linear(m, flags.NUM_CLASS)
+        # fast path: the whole sparseModel inside the C++ executor (same kernels, one autograd node);
+        # m must be a multiple of 16 (MFMA tiles).  use_executor=False keeps the per-layer path.
+        self.use_executor = (dimension == 3 and m % 16 == 0)
+        self._executor = None
+
+    def _trunk(self, coords, features):
+        if self._executor is None:
+            f = self._flags
+            self._executor = TrunkExecutor(self.sparseModel, f.URESNET_FILTERS, f.URESNET_NUM_STRIDES, 2, f.NUM_CLASS)
+        ex = self._executor
+        inp = self.sparseModel[0]
+        c = coords.to(torch.int32) if coords.dtype != torch.int32 else coords
+        geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels)
+        ex.flatten(c.device)
+        return ex.forward(geo, so.input_features(geo, features), True)
 
     def forward(self, point_cloud):
         """point_cloud: (N, d+2) rows [x, y, z, batch_id, value]; returns [ (N, NUM_CLASS) ]."""
         coords = point_cloud[:, 0:-1].float()
         features = point_cloud[:, -1][:, None].float()
-        x = self.sparseModel((coords, features))
+        if self.use_executor and self.training and coords.is_cuda:
+            x = self._trunk(coords, features)
+        else:
+            x = self.sparseModel((coords, features))
         x = self.linear(x)
         return [x]
 

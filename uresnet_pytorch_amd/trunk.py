@@ -1,0 +1,196 @@
+"""Fast path for the sparse trunk: the whole `sparseModel` (stem conv + UNet + final BNReLU +
+OutputLayer) runs inside liburesnet_hip.so's executor (csrc/urn_net.hip) instead of one
+autograd node per layer.  Same kernels, same results; the per-layer module tree stays the
+flexible path (eval mode, hooks, tests).
+
+Parameters of the module tree are re-pointed to views of ONE flat fp32 tensor (registration
+order), BatchNorm running statistics likewise, and gradients are written straight into the flat
+gradient buffer that the parameters' .grad tensors alias -- one memset and one all-reduce per step.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import lib as _l
+from . import scn
+from . import sparse_ops as so
+
+
+class _Token:
+    """Lives as long as the autograd node of one forward; a slot is busy while its token is alive."""
+    pass
+
+
+class _Slot:
+    """One executor handle (it holds the tape of its last forward) plus its workspace."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        self.token = None
+        self.ws = None
+        self.ws_bytes = 0
+
+    def busy(self):
+        return self.token is not None and self.token() is not None
+
+
+class TrunkExecutor:
+    def __init__(self, sparse_model, m, num_levels, reps, num_class):
+        self.model = sparse_model
+        self.cfg = (m, num_levels, reps, num_class)
+        self.handle = None
+        self.slots = []
+        self.flat = None
+        self.running = None
+        self.flat_grad = None
+
+    # -- handle ------------------------------------------------------------------------
+    def _new_handle(self):
+        L = _l.load()
+        h = ctypes.c_void_p()
+        _l.check(L.urn_net_create(*self.cfg, float(self.eps), float(self.momentum), ctypes.byref(h)), 'net_create')
+        return h
+
+    def acquire(self):
+        """A slot whose last forward has been consumed by backward (or dropped)."""
+        for s in self.slots:
+            if not s.busy():
+                return s
+        s = _Slot(self.handle if not self.slots else self._new_handle())
+        self.slots.append(s)
+        return s
+
+    def _create(self):
+        L = _l.load()
+        bn = [mod for mod in self.model.modules() if isinstance(mod, scn.BatchNormLeakyReLU)]
+        self.eps = bn[0].eps if bn else 1e-4
+        self.momentum = bn[0].momentum if bn else 0.9
+        h = self._new_handle()
+        self.handle = h
+        self.params = [p for p in self.model.parameters()]
+        self.bns = bn
+        nt = L.urn_net_num_tensors(h)
+        assert nt == len(self.params), 'executor and module tree disagree on the number of tensors (%d vs %d)' % (
+            nt, len(self.params))
+        self.offsets = []
+        off, num = ctypes.c_int64(), ctypes.c_int64()
+        for i, p in enumerate(self.params):
+            _l.check(L.urn_net_tensor(h, i, ctypes.byref(off), ctypes.byref(num)))
+            assert num.value == p.numel(), 'tensor %d: %d vs %d elements' % (i, num.value, p.numel())
+            self.offsets.append(off.value)
+        self.n_params = L.urn_net_param_count(h)
+        self.n_running = L.urn_net_running_count(h)
+        assert self.n_running == sum(2 * b.nPlanes for b in bn)
+
+    def __del__(self):
+        try:
+            handles = [s.handle for s in self.slots] or ([self.handle] if self.handle is not None else [])
+            for h in handles:
+                _l.load().urn_net_destroy(h)
+        except Exception:
+            pass
+
+    # -- flat storage ------------------------------------------------------------------
+    def _aliased(self, dev):
+        if self.flat is None or self.flat.device != dev:
+            return False
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def flatten(self, dev):
+        """(Re)point parameters and BN buffers at the flat tensors; values are preserved."""
+        if self.handle is None:
+            self._create()
+        if self._aliased(dev):
+            return
+        flat = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        running = torch.empty(max(self.n_running, 1), dtype=torch.float32, device=dev)
+        o = 0
+        for b in self.bns:
+            c = b.nPlanes
+            running[o:o + c].copy_(b.running_mean); running[o + c:o + 2 * c].copy_(b.running_var)
+            b.running_mean = running[o:o + c]; b.running_var = running[o + c:o + 2 * c]
+            o += 2 * c
+        self.flat, self.running = flat, running
+        self.flat_grad = None
+
+    def grad_buffer(self):
+        """Flat gradient buffer that every trunk parameter's .grad aliases.  Adopts an existing flat
+        buffer (parallel.FlatGradients) when the .grad tensors already sit at the right offsets."""
+        g0 = self.params[0].grad
+        if g0 is not None:
+            base = g0.data_ptr() - 4 * self.offsets[0]
+            if all(p.grad is not None and p.grad.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets)):
+                return base, None
+        if self.flat_grad is None or self.flat_grad.device != self.flat.device:
+            self.flat_grad = torch.zeros(self.n_params, dtype=torch.float32, device=self.flat.device)
+        fresh = all(p.grad is None for p in self.params)
+        if not fresh:
+            # gradients exist elsewhere (accumulation by the user): carry them over once
+            for p, o in zip(self.params, self.offsets):
+                if p.grad is not None and p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                    self.flat_grad[o:o + p.numel()].copy_(p.grad.reshape(-1))
+        else:
+            self.flat_grad.zero_()      # zero_grad(set_to_none=True) semantics
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        return self.flat_grad.data_ptr(), self.flat_grad
+
+    def workspace(self, slot, geo, with_backward):
+        L = _l.load()
+        n = (ctypes.c_int64 * geo.num_levels)(*geo.n)
+        need = L.urn_net_workspace_bytes(slot.handle, geo.num_levels, n, geo.n_rows, int(with_backward))
+        if need < 0:
+            raise RuntimeError('urn_net_workspace_bytes failed')
+        if slot.ws is None or slot.ws_bytes < need or slot.ws.device != geo.device:
+            slot.ws_bytes = int(need * 1.25)
+            slot.ws = torch.empty(slot.ws_bytes, dtype=torch.uint8, device=geo.device)
+        return slot.ws, slot.ws_bytes
+
+    def forward(self, geo, feats, training):
+        """site features -> (n_rows, m) rows in input order.  Recorded for backward when training."""
+        need_bwd = bool(training and torch.is_grad_enabled())   # grad mode is off inside Function.forward
+        return _TrunkFunction.apply(feats, self.params[0], self, geo, need_bwd)
+
+
+class _TrunkFunction(torch.autograd.Function):
+    """The trunk as one autograd node.  The stem weight rides along as an input only so that
+    autograd schedules backward(); parameter gradients are written into the flat gradient
+    buffer directly (the parameters' .grad tensors alias it)."""
+
+    @staticmethod
+    def forward(ctx, feats, anchor, ex, geo, need_bwd):
+        L = _l.load()
+        Lv = geo.num_levels
+        training = True
+        slot = ex.acquire()
+        ws, ws_bytes = ex.workspace(slot, geo, need_bwd)
+        n = (ctypes.c_int64 * Lv)(*geo.n)
+        nbr = (ctypes.c_void_p * Lv)(*[t.data_ptr() for t in geo.nbr])
+        chd = (ctypes.c_void_p * Lv)(*([t.data_ptr() for t in geo.chd] + [None]))
+        up = (ctypes.c_void_p * Lv)(*([t.data_ptr() for t in geo.up] + [None]))
+        m = ex.cfg[0]
+        out = torch.empty((geo.n_rows, m), dtype=torch.float32, device=feats.device)
+        feats = feats.contiguous()
+        _l.check(L.urn_net_forward(slot.handle, Lv, geo.ld, n, nbr, chd, up, geo.row2site.data_ptr(), geo.n_rows,
+                                   ex.flat.data_ptr(), ex.running.data_ptr(), feats.data_ptr(), ws.data_ptr(),
+                                   ws_bytes, out.data_ptr(), int(training), _l.stream()), 'net_forward')
+        ctx.ex, ctx.geo, ctx.ws, ctx.feats, ctx.slot = ex, geo, ws, feats, slot   # keep workspace/inputs alive
+        if need_bwd:
+            ctx.token = _Token()
+            slot.token = weakref.ref(ctx.token)    # busy until backward ran or the graph is dropped
+        return out
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        L = _l.load()
+        ex = ctx.ex
+        gptr, keep = ex.grad_buffer()
+        d_rows = d_rows.contiguous()
+        _l.check(L.urn_net_backward(ctx.slot.handle, d_rows.data_ptr(), gptr, _l.stream()), 'net_backward')
+        ctx.slot.token = None
+        return None, None, None, None, None
