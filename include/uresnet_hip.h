@@ -106,6 +106,7 @@ int urn_transpose_w(const float *w, int K, int a, int b, float *wt, void *stream
 /* scn.BatchNormReLU / BatchNormLeakyReLU(leak 0) over the (n, c) row matrix, batch
  * statistics (biased variance), fp64 accumulation.  scratch: urn_bn_scratch_bytes(c).
  * mean/invstd (c) are outputs of fwd and inputs of bwd.  relu: 0/1.
+ * bwd ACCUMULATES into dgamma/dbeta (caller zeroes), like every parameter gradient here.
  * running_mean/var may be NULL; otherwise updated with `momentum` (new = m*old + (1-m)*batch). */
 int64_t urn_bn_scratch_bytes(int c);
 int urn_bn_relu_fwd(const float *x, int64_t n, int c, const float *gamma, const float *beta,

@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const double *__restrict__ 
             if (r1p) r1p[col] = (float)(momentum * r1p[col] + (1.0 - momentum) * v);
         } else {
             double invn = n > 0 ? 1.0 / (double)n : 0.0;
-            o1[col] = (float)v0;            // dbeta
-            o0[col] = (float)v1;            // dgamma
+            o1[col] += (float)v0;           // dbeta  (accumulated, like every parameter gradient)
+            o0[col] += (float)v1;           // dgamma
             r0p[col] = (float)(v0 * invn);  // coef[0][col]
             r1p[col] = (float)(v1 * invn);  // coef[1][col]
         }

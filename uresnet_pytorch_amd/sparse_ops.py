@@ -195,8 +195,8 @@ class BNReLUFunction(torch.autograd.Function):
         n, c = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg = torch.empty(c, dtype=torch.float32, device=x.device)
-        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        dg = torch.zeros(c, dtype=torch.float32, device=x.device)   # the kernel accumulates
+        db = torch.zeros(c, dtype=torch.float32, device=x.device)
         scratch = torch.empty(L.urn_bn_scratch_bytes(c), dtype=torch.uint8, device=x.device)
         _l.check(L.urn_bn_relu_bwd(_l.ptr(x), _l.ptr(y), _l.ptr(dy), n, c, _l.ptr(gamma), _l.ptr(mean),
                                    _l.ptr(invstd), ctx.relu, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
