@@ -10,6 +10,7 @@
 // each (registration order of the module tree), which is also what the single RCCL
 // all-reduce per step consumes.
 #include "urn_common.h"
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -71,6 +72,12 @@ struct urn_net {
     float *running = nullptr, *grads = nullptr;
     int training = 1;
     hipStream_t st = nullptr;
+    hipStream_t side = nullptr;          // weight gradients run here, off the dX -> BN critical path
+    std::vector<hipEvent_t> events;
+    size_t ev_next = 0;
+    bool side_used = false;
+    float *wt_all = nullptr;             // transposed copy of every conv weight, same offsets as params
+    std::vector<ConvP *> convs;          // every conv, for the batched transpose
     int rc = URN_OK;
     float *trunk_out = nullptr;   // (n0, m) features after the last BNReLU
 
@@ -118,12 +125,8 @@ struct urn_net {
     float *conv_fwd(ConvP &c, const float *x, const int32_t *tbl, int64_t n_out, const float *res)
     {
         c.x = x;
-        float *wt = arena.f32((int64_t)c.K * c.cin * c.cout);
         float *y = arena.f32(n_out * c.cout);
-        if (live()) {
-            check(urn_transpose_w(params + c.w, c.K, c.cin, c.cout, wt, st));
-            check(urn_gconv_fwd(x, wt, tbl, geo.ld, c.K, 0, n_out, c.cin, c.cout, res, y, st));
-        }
+        if (live()) check(urn_gconv_fwd(x, wt_all + c.w, tbl, geo.ld, c.K, 0, n_out, c.cin, c.cout, res, y, st));
         return y;
     }
     // returns dx (n_in, cin); accumulates dW into grads
@@ -133,7 +136,16 @@ struct urn_net {
         float *dx = need_dx ? arena.f32(n_in * c.cin) : nullptr;
         if (live()) {
             if (need_dx) check(urn_gconv_fwd(dy, params + c.w, tbl_b, geo.ld, c.K, flip_b, n_in, c.cout, c.cin, nullptr, dx, st));
-            check(urn_gconv_bwd_dw(c.x, dy, tbl_f, geo.ld, c.K, n_out, c.cin, c.cout, grads + c.w, st));
+            hipStream_t ws = st;
+            if (side && !events.empty()) {
+                // fork: dy (and everything before it) is complete on the main stream at this point
+                hipEvent_t e = events[ev_next++ % events.size()];
+                if (hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess) {
+                    ws = side;
+                    side_used = true;
+                }
+            }
+            check(urn_gconv_bwd_dw(c.x, dy, tbl_f, geo.ld, c.K, n_out, c.cin, c.cout, grads + c.w, ws));
         }
         return dx;
     }
@@ -266,11 +278,72 @@ extern "C" int urn_net_create(int m, int num_levels, int reps, int num_class, do
     n->stem = n->make_conv(27, 1, m);
     n->make_u(n->u, 0);
     n->bn_out = n->make_bn(m);
+    // side stream + a ring of events for the fork/join of the weight-gradient kernels; if the runtime is not
+    // available (no GPU: build check, workspace sizing) the executor stays single-stream
+    if (hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking) == hipSuccess) {
+        for (int i = 0; i < 128; ++i) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
+            n->events.push_back(e);
+        }
+    } else {
+        n->side = nullptr;
+        (void)hipGetLastError();
+    }
     *out = n;
     return URN_OK;
 }
 
-extern "C" void urn_net_destroy(urn_net *n) { delete n; }
+extern "C" void urn_net_destroy(urn_net *n)
+{
+    if (!n) return;
+    for (auto e : n->events) (void)hipEventDestroy(e);
+    if (n->side) (void)hipStreamDestroy(n->side);
+    delete n;
+}
+
+// ---- batched weight transpose: every conv weight (K, a, b) -> (K, b, a) in one launch ----------
+#define URN_MAX_CONVS 96
+struct TDesc { int K, a, b; long off; };
+struct TDescs { int n; TDesc d[URN_MAX_CONVS]; };
+
+__global__ void k_transpose_all(TDescs t, const float *__restrict__ params, float *__restrict__ wt)
+{
+    const TDesc d = t.d[blockIdx.y];
+    const long per = (long)d.a * d.b, total = per * d.K;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long o = e / per, rem = e - o * per;
+        const int j = (int)(rem / d.a), i = (int)(rem - (long)j * d.a);   // wt[o][j][i] = w[o][i][j]
+        wt[d.off + e] = params[d.off + o * per + (long)i * d.b + j];
+    }
+}
+
+static void collect_convs(urn_net *net, ULevel &lv)
+{
+    for (auto &k : lv.pre) { if (k.has_nin) net->convs.push_back(&k.nin); net->convs.push_back(&k.conv1); net->convs.push_back(&k.conv2); }
+    if (lv.has_sub) {
+        net->convs.push_back(&lv.down);
+        collect_convs(net, *lv.sub);
+        net->convs.push_back(&lv.up);
+    }
+    for (auto &k : lv.post) { if (k.has_nin) net->convs.push_back(&k.nin); net->convs.push_back(&k.conv1); net->convs.push_back(&k.conv2); }
+}
+
+static void transpose_all(urn_net *net)
+{
+    if (net->convs.empty()) { net->convs.push_back(&net->stem); collect_convs(net, net->u); }
+    net->wt_all = net->arena.f32(net->n_params);
+    if (!net->live()) return;
+    for (size_t base = 0; base < net->convs.size(); base += URN_MAX_CONVS) {
+        TDescs t;
+        t.n = (int)std::min((size_t)URN_MAX_CONVS, net->convs.size() - base);
+        for (int i = 0; i < t.n; ++i) {
+            const ConvP *c = net->convs[base + i];
+            t.d[i] = TDesc{c->K, c->cin, c->cout, (long)c->w};
+        }
+        hipLaunchKernelGGL(k_transpose_all, dim3(32, t.n), dim3(256), 0, net->st, t, net->params, net->wt_all);
+    }
+}
 extern "C" int64_t urn_net_param_count(const urn_net *n) { return n ? n->n_params : -1; }
 extern "C" int64_t urn_net_running_count(const urn_net *n) { return n ? n->n_running : -1; }
 extern "C" int urn_net_num_tensors(const urn_net *n) { return n ? (int)n->p_off.size() : -1; }
@@ -301,6 +374,7 @@ static int set_geo(urn_net *net, int num_levels, int64_t ld, const int64_t *n, c
 
 static void run_forward(urn_net *net, const float *site_feats)
 {
+    transpose_all(net);
     float *x = net->conv_fwd(net->stem, site_feats, net->geo.nbr[0], net->geo.n[0], nullptr);
     x = net->u_fwd(net->u, x, 0);
     net->trunk_out = net->bn_fwd(net->bn_out, x, net->geo.n[0]);
@@ -318,6 +392,12 @@ static void run_backward(urn_net *net, const float *d_rows)
     d = net->bn_bwd(net->bn_out, d, n0);
     d = net->u_bwd(net->u, d, 0);
     net->conv_bwd(net->stem, d, net->geo.nbr[0], net->geo.nbr[0], 1, n0, n0, false);
+    // join: the caller's stream continues only after every weight gradient has landed
+    if (net->side_used && net->live()) {
+        hipEvent_t e = net->events[net->ev_next++ % net->events.size()];
+        net->check(hipEventRecord(e, net->side) == hipSuccess && hipStreamWaitEvent(net->st, e, 0) == hipSuccess ? URN_OK : URN_EHIP);
+        net->side_used = false;
+    }
 }
 
 // Workspace needed by one forward (+ backward when with_backward) for the given level sizes.
