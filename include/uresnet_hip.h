@@ -120,6 +120,50 @@ int urn_bn_relu_bwd(const float *x, const float *y, const float *dy, int64_t n, 
                     const float *gamma, const float *mean, const float *invstd, int relu,
                     float *dx, float *dgamma, float *dbeta, void *scratch, void *stream);
 
+/* ---- fused BatchNorm+ReLU pieces (what the executor uses) --------------------------------
+ * The BatchNorm passes are folded into the neighbouring gather convolutions:
+ *   forward : the producing conv writes per-tile column partials (sum, sum of squares; fp64) of its
+ *             output [epilogue 1]; urn_bn_finalize_fwd turns them into mean/invstd and the folded
+ *             affine scale = gamma*invstd, shift = beta - mean*scale; the consuming conv applies
+ *             relu(x*scale + shift) to the rows it gathers [xf_scale/xf_shift] -- the normalised
+ *             tensor never exists in HBM;
+ *   backward: the conv computing the gradient w.r.t. the BatchNorm OUTPUT applies the ReLU mask and
+ *             reduces (sum g, sum g*xhat) per tile [epilogue 2]; urn_bn_finalize_bwd accumulates
+ *             dgamma/dbeta and emits the two coefficients; urn_bn_bwd_apply forms
+ *             dx = gamma*invstd*(g - c0 - xhat*c1) (+ extra, e.g. the residual branch's gradient).
+ * Partial slabs are [n_part][2][c] doubles, summed in a fixed order (deterministic). */
+typedef struct {
+    const float *x, *wt;           /* gathered rows (n_in, cin); weights pre-transposed (K, cout, cin) */
+    const int32_t *tbl;            /* [K][ld] */
+    int64_t ld;
+    int K, flip;
+    int64_t n_out;
+    int cin, cout;
+    const float *res;              /* optional residual added to y */
+    float *y;
+    const float *xf_scale, *xf_shift; /* optional (cin): rows are used as relu(x*scale+shift) */
+    int epilogue;                  /* 0 none | 1 column stats of y | 2 BatchNorm-backward reduce */
+    double *part;                  /* epilogue != 0: slab of urn_gconv_part_bytes(n_out, cout) bytes */
+    const float *e_x, *e_scale, *e_shift, *e_mean, *e_invstd; /* epilogue 2: the BatchNorm's input (n_out, cout) and folded affine */
+} urn_gconv_args;
+int64_t urn_gconv_part_bytes(int64_t n_out, int cout);
+int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);
+/* weight gradient with the same input transform: x rows are used as relu(x*scale+shift) */
+int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const float *xf_shift, const float *dy,
+                        const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw,
+                        void *stream);
+/* column partials of a tensor whose producer cannot fuse them (the 1-channel stem) */
+int urn_bn_stats_partial(const float *x, int64_t n, int c, double *part, int *n_part, void *stream);
+int urn_bn_finalize_fwd(const double *part, int n_part, int64_t n, int c, int part_ld, double eps,
+                        const float *gamma, const float *beta, float *mean, float *invstd, float *scale,
+                        float *shift, float *running_mean, float *running_var, double momentum,
+                        void *stream);
+int urn_bn_finalize_bwd(const double *part, int n_part, int64_t n, int c, float *dgamma, float *dbeta,
+                        float *coef0, float *coef1, void *stream);
+int urn_bn_bwd_apply(const float *x, const float *g, const float *extra, int64_t n, int c,
+                     const float *gamma, const float *mean, const float *invstd, const float *coef0,
+                     const float *coef1, float *dx, void *stream);
+
 /* scn.OutputLayer (reference uresnet_sparse.py:24): y[i,:] = x[idx[i],:]; and its
  * backward dx[idx[i],:] += dy[i,:] (fp32 atomics; caller zeroes dx). */
 int urn_rows_gather(const float *x, const int32_t *idx, int64_t n, int c, float *y, void *stream);
@@ -136,7 +180,10 @@ int urn_rows_scatter_add(const float *dy, const int32_t *idx, int64_t n, int c, 
  * urn_net_backward replays the LAST urn_net_forward of the same handle and needs the same
  * workspace untouched; it ACCUMULATES into `grads` (caller zeroes). */
 typedef struct urn_net urn_net;
-int urn_net_create(int m, int num_levels, int reps, int num_class, double eps, double momentum, urn_net **out);
+#define URN_NET_UNFUSED 1        /* keep BatchNorm as separate passes (debug / A-B) */
+#define URN_NET_SINGLE_STREAM 2  /* do not run weight gradients on a side stream */
+int urn_net_create(int m, int num_levels, int reps, int num_class, double eps, double momentum, int flags,
+                   urn_net **out);
 void urn_net_destroy(urn_net *net);
 int64_t urn_net_param_count(const urn_net *net);
 int64_t urn_net_running_count(const urn_net *net);
@@ -154,6 +201,8 @@ int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stre
  * kind 0 = gather-conv forward/input-gradient kernel, 1 = weight-gradient kernel.
  * urn_prof_enable resets the records; urn_prof_read waits for the recorded events. */
 int urn_prof_enable(int on);
+/* tuning knobs for A/B measurements: "gconv_pipe" (0/1), "gconv_min_waves" */
+int urn_set_option(const char *key, int64_t value);
 int urn_prof_read(int kind, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus

@@ -236,29 +236,103 @@ def test_network_cfg3_full_size(dev):
 
 
 def test_executor_matches_per_layer_path(dev):
-    """The C++ whole-network executor and the per-layer autograd path issue the same kernels:
-    identical logits (bitwise), gradients equal up to the fp32 atomics order of the weight gradient."""
+    """The C++ whole-network executor against the per-layer autograd path.
+    Unfused executor (URN_NET_UNFUSED): the same kernels in the same order -> identical logits (bitwise),
+    gradients equal up to the fp32 atomics order of the weight gradient.
+    Fused executor (default; BatchNorm folded into the convolutions): same maths, different rounding
+    (relu(x*scale+shift) instead of relu((x-mean)*a+beta)) -> 1e-5 relative."""
     from uresnet_pytorch_amd.models import SparseSegmentationLoss
     S, m, L, nc = 64, 16, 4, 5
     blob = make_sparse_blob([5, 6], S, 3000)
     flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=L, SPATIAL_SIZE=S, NUM_CLASS=nc)
     P = orc.init_params(m, L, nc, seed=2)
     data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
-    outs, grads, runs = [], [], []
-    for use_ex in (True, False):
+    res = {}
+    for name, use_ex, fl in (('fused', True, 0), ('unfused', True, 1), ('layers', False, 0)):
         net = make_model(flags, P, dev)
         net.use_executor = use_ex
+        net.executor_flags = fl
         out = net(data)
         loss, _ = SparseSegmentationLoss(flags)(out, [data], [label], None)
         loss.backward()
-        outs.append(out[0].detach().cpu().numpy())
-        grads.append({k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()})
-        runs.append({k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items() if 'running' in k})
-    assert np.array_equal(outs[0], outs[1])
-    for k in grads[0]:
-        assert rel(grads[0][k], grads[1][k]) < 1e-5, k
-    for k in runs[0]:
-        assert np.array_equal(runs[0][k], runs[1][k]), k      # running statistics updated identically
+        res[name] = (out[0].detach().cpu().numpy(),
+                     {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()},
+                     {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items() if 'running' in k})
+    assert np.array_equal(res['unfused'][0], res['layers'][0])
+    for k in res['layers'][1]:
+        assert rel(res['unfused'][1][k], res['layers'][1][k]) < 1e-5, k
+    for k in res['layers'][2]:
+        assert np.array_equal(res['unfused'][2][k], res['layers'][2][k]), k
+    assert rel(res['fused'][0], res['layers'][0]) < 1e-5
+    for k in res['layers'][1]:
+        assert rel(res['fused'][1][k], res['layers'][1][k]) < 5e-5, k
+    for k in res['layers'][2]:
+        assert rel(res['fused'][2][k], res['layers'][2][k]) < 1e-6, k
+
+
+def test_fused_conv_pieces_vs_oracle(dev):
+    """urn_gconv_fwd_ex: BatchNormReLU folded into the load, column statistics epilogue, BatchNorm-backward
+    reduce epilogue; urn_gconv_bwd_dw_ex with the same input transform -- each against the oracle."""
+    import ctypes
+    from uresnet_pytorch_amd import lib as L_, sparse_ops as so
+    L = L_.load()
+    S, cin, cout = 32, 32, 48
+    c, f = cloud(9, S, 1500, 2, 0)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
+    ref = orc.Geometry(c, f, S, 1)
+    n = ref.n[0]
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    g_, b_ = (1 + 0.1 * rng.normal(size=cin)).astype(np.float32), (0.1 * rng.normal(size=cin)).astype(np.float32)
+    u_ref, mean, invstd = orc.bn_relu_fwd(x, g_, b_, True)
+    scale = (g_ * invstd).astype(np.float32); shift = (b_ - mean * scale).astype(np.float32)
+    y_ref = orc.conv_fwd(u_ref, W, ref.nbr[0])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xt, Wt, sc, sh = t(x), t(W), t(scale), t(shift)
+    wt = so._transpose_w(Wt)
+    y = torch.empty((n, cout), device=dev)
+    part = torch.zeros(L.urn_gconv_part_bytes(n, cout) // 8, dtype=torch.float64, device=dev)
+
+    class A(ctypes.Structure):
+        _fields_ = [('x', ctypes.c_void_p), ('wt', ctypes.c_void_p), ('tbl', ctypes.c_void_p), ('ld', ctypes.c_int64),
+                    ('K', ctypes.c_int), ('flip', ctypes.c_int), ('n_out', ctypes.c_int64), ('cin', ctypes.c_int),
+                    ('cout', ctypes.c_int), ('res', ctypes.c_void_p), ('y', ctypes.c_void_p),
+                    ('xf_scale', ctypes.c_void_p), ('xf_shift', ctypes.c_void_p), ('epilogue', ctypes.c_int),
+                    ('part', ctypes.c_void_p), ('e_x', ctypes.c_void_p), ('e_scale', ctypes.c_void_p),
+                    ('e_shift', ctypes.c_void_p), ('e_mean', ctypes.c_void_p), ('e_invstd', ctypes.c_void_p)]
+    npart = ctypes.c_int()
+    a = A(xt.data_ptr(), wt.data_ptr(), geo.nbr[0].data_ptr(), geo.ld, 27, 0, n, cin, cout, None, y.data_ptr(),
+          sc.data_ptr(), sh.data_ptr(), 1, part.data_ptr(), None, None, None, None, None)
+    L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a), ctypes.byref(npart), L_.stream()))
+    assert rel(y.cpu().numpy(), y_ref) < TOL
+    pp = part[:npart.value * 2 * cout].view(npart.value, 2, cout).sum(0).cpu().numpy()
+    assert rel(pp[0], y_ref.astype(np.float64).sum(0)) < 1e-6 and rel(pp[1], (y_ref.astype(np.float64) ** 2).sum(0)) < 1e-6
+    # weight gradient with the transform
+    dy = rng.normal(size=(n, cout)).astype(np.float32)
+    dW = torch.zeros_like(Wt)
+    L_.check(L.urn_gconv_bwd_dw_ex(xt.data_ptr(), sc.data_ptr(), sh.data_ptr(), t(dy).data_ptr(), geo.nbr[0].data_ptr(),
+                                   geo.ld, 27, n, cin, cout, dW.data_ptr(), L_.stream()))
+    du_ref, dW_ref = orc.conv_bwd(u_ref, W, ref.nbr[0], dy, ref.nbr_inv[0])
+    assert rel(dW.cpu().numpy(), dW_ref) < TOL
+    # input gradient with the BatchNorm-backward reduce epilogue, then finalize + apply == oracle BN backward
+    gbuf = torch.empty((n, cin), device=dev)
+    part2 = torch.zeros(L.urn_gconv_part_bytes(n, cin) // 8, dtype=torch.float64, device=dev)
+    mt, it = t(mean), t(invstd)
+    a2 = A(t(dy).data_ptr(), Wt.data_ptr(), geo.nbr[0].data_ptr(), geo.ld, 27, 1, n, cout, cin, None, gbuf.data_ptr(),
+           None, None, 2, part2.data_ptr(), xt.data_ptr(), sc.data_ptr(), sh.data_ptr(), mt.data_ptr(), it.data_ptr())
+    dyt = t(dy); a2.x = dyt.data_ptr()
+    L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a2), ctypes.byref(npart), L_.stream()))
+    dg = torch.zeros(cin, device=dev); db = torch.zeros(cin, device=dev); coef = torch.empty(2 * cin, device=dev)
+    L_.check(L.urn_bn_finalize_bwd(part2.data_ptr(), npart.value, n, cin, dg.data_ptr(), db.data_ptr(), coef.data_ptr(),
+                                   coef.data_ptr() + 4 * cin, L_.stream()))
+    extra = rng.normal(size=(n, cin)).astype(np.float32)
+    dx = torch.empty((n, cin), device=dev)
+    L_.check(L.urn_bn_bwd_apply(xt.data_ptr(), gbuf.data_ptr(), t(extra).data_ptr(), n, cin, t(g_).data_ptr(), mt.data_ptr(),
+                                it.data_ptr(), coef.data_ptr(), coef.data_ptr() + 4 * cin, dx.data_ptr(), L_.stream()))
+    dx_ref, dg_ref, db_ref = orc.bn_relu_bwd(x, u_ref, du_ref, g_, mean, invstd, True)
+    assert rel(dx.cpu().numpy(), dx_ref + extra) < 5 * TOL
+    assert rel(dg.cpu().numpy(), dg_ref) < 5 * TOL and rel(db.cpu().numpy(), db_ref) < 5 * TOL
 
 
 def test_executor_two_forwards_before_backward(dev):

@@ -1,0 +1,34 @@
+"""A/B of executor switches in ONE process (interleaved rounds): fused vs unfused BatchNorm,
+weight gradients on a side stream vs single stream.  Run on the GPU box."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from types import SimpleNamespace
+import numpy as np
+import torch
+from uresnet_pytorch_amd import parallel
+from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
+from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
+
+dev = torch.device('cuda:0')
+flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=5, SPATIAL_SIZE=512, NUM_CLASS=5)
+blob = make_sparse_blob([0], 512, 50000)
+data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
+crit = SparseSegmentationLoss(flags)
+variants = {}
+for name, fl in (('fused+side', 0), ('unfused+side', 1), ('fused+single', 2), ('unfused+single', 3)):
+    torch.manual_seed(0)
+    net = SparseUResNet(flags).to(dev).train(); net.executor_flags = fl
+    g = parallel.FlatGradients(net); opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    def step(net=net, g=g, opt=opt):
+        g.zero(); out = net(data); loss, _ = crit(out, [data], [label], None); loss.backward(); opt.step()
+    variants[name] = step
+for s in variants.values():
+    for _ in range(5): s()
+res = {k: [] for k in variants}
+for rnd in range(5):
+    for k, s in variants.items():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): s()
+        torch.cuda.synchronize(); res[k].append((time.perf_counter() - t0) / 20 * 1e3)
+for k, v in res.items():
+    print('%-16s median %.3f ms  min %.3f ms' % (k, float(np.median(v)), min(v)))

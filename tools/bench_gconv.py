@@ -1,0 +1,32 @@
+"""Micro-benchmark of the gather-conv kernel on the real cfg3 geometry, variants interleaved in one process."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from uresnet_pytorch_amd import lib as L_, sparse_ops as so
+from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
+L = L_.load(); dev = torch.device('cuda:0')
+blob = make_sparse_blob([0], 512, 50000)
+geo = so.SparseGeometry(torch.from_numpy(blob['data'][:, :4].astype(np.int32)).to(dev), 512, 5)
+print('n', geo.n, 'rules', geo.rules)
+def run(level, cin, cout, reps=30):
+    n = geo.n[level]
+    x = torch.randn(n, cin, device=dev); wt = torch.randn(27, cout, cin, device=dev) * 0.05; y = torch.empty(n, cout, device=dev)
+    def call():
+        L_.check(L.urn_gconv_fwd(x.data_ptr(), wt.data_ptr(), geo.nbr[level].data_ptr(), geo.ld, 27, 0, n, cin, cout, None, y.data_ptr(), L_.stream()))
+    for _ in range(3): call()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): call()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+shapes = [(0, 16, 16), (1, 32, 32), (2, 48, 48), (3, 64, 64), (4, 80, 80), (3, 128, 64), (2, 96, 48)]
+variants = [('pipe1 mw8192', 1, 8192), ('pipe0 mw8192', 0, 8192), ('pipe1 mw2048', 1, 2048), ('pipe0 mw2048', 0, 2048), ('pipe0 mw512', 0, 512), ('pipe1 mw512', 1, 512)]
+for lv, ci, co in shapes:
+    out = []
+    for name, pipe, mw in variants:
+        L.urn_set_option(b'gconv_pipe', pipe); L.urn_set_option(b'gconv_min_waves', mw)
+        t = min(run(lv, ci, co) for _ in range(3))
+        out.append('%s %.1f' % (name, t))
+    fl = 2.0 * geo.rules[lv] * ci * co
+    print('L%d %3d->%3d  n=%6d  %s   [useful %.2f GF]' % (lv, ci, co, geo.n[lv], ' | '.join(out), fl / 1e9))

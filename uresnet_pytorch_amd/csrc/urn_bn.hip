@@ -102,24 +102,29 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
 // Second stage: 16 columns per block, 16 lanes per column sweep the block partials in a fixed order.
 // mode 0 -> mean/invstd (+ running stats); mode 1 -> dgamma/dbeta and the two backward coefficients.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bn_finalize(const double *__restrict__ part, int nblk, long n, int c,
+__global__ __launch_bounds__(1024) void k_bn_finalize(const double *__restrict__ part, int nblk, long n, int c,
                                                      double eps, float *__restrict__ o0, float *__restrict__ o1,
                                                      float *r0p, float *r1p, double momentum)
 {
-    __shared__ double s0[256], s1[256];
-    const int t = threadIdx.x, cl = t & 15, bg = t >> 4;
+    __shared__ double s0[1024], s1[1024];
+    const int t = threadIdx.x, cl = t & 15, bg = t >> 4, G = blockDim.x >> 4;
     const int col = blockIdx.x * 16 + cl;
-    double a0 = 0.0, a1 = 0.0;
-    if (col < c)
-        for (int b = bg; b < nblk; b += 16) {
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    if (col < c) {
+        int b = bg;
+        for (; b + G < nblk; b += 2 * G) {   // two partials in flight per lane
             a0 += part[((long)b * 2) * c + col];
             a1 += part[((long)b * 2 + 1) * c + col];
+            b0 += part[((long)(b + G) * 2) * c + col];
+            b1 += part[((long)(b + G) * 2 + 1) * c + col];
         }
-    s0[t] = a0; s1[t] = a1;
+        if (b < nblk) { a0 += part[((long)b * 2) * c + col]; a1 += part[((long)b * 2 + 1) * c + col]; }
+    }
+    s0[t] = a0 + b0; s1[t] = a1 + b1;
     __syncthreads();
     if (t < 16 && col < c) {
         double v0 = 0.0, v1 = 0.0;
-        for (int j = 0; j < 16; ++j) { v0 += s0[j * 16 + t]; v1 += s1[j * 16 + t]; }
+        for (int j = 0; j < G; ++j) { v0 += s0[j * 16 + t]; v1 += s1[j * 16 + t]; }
         if (MODE == 0) {
             double m = n > 0 ? v0 / (double)n : 0.0;
             double v = n > 0 ? v1 / (double)n - m * m : 0.0;
@@ -263,7 +268,7 @@ extern "C" int urn_bn_relu_fwd(const float *x, int64_t n, int c, const float *ga
         hipLaunchKernelGGL((k_bn_partial<0, 1>), dim3(nblk), dim3(256), 0, st, x, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (long)n, c, 0, rpb,
                            part);
-    hipLaunchKernelGGL(k_bn_finalize<0>, dim3(urn_cdiv(c, 16)), dim3(256), 0, st, part, nblk, (long)n, c, eps, mean,
+    hipLaunchKernelGGL(k_bn_finalize<0>, dim3(urn_cdiv(c, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, part, nblk, (long)n, c, eps, mean,
                        invstd, running_mean, running_var, momentum);
     URN_LAUNCH_CHECK();
     return urn_bn_relu_apply(x, n, c, gamma, beta, mean, invstd, relu, y, stream);
@@ -288,7 +293,7 @@ extern "C" int urn_bn_relu_bwd(const float *x, const float *y, const float *dy, 
     else
         hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3(nblk), dim3(256), 0, st, x, y, dy, mean, invstd, (long)n, c, relu,
                            rpb, part);
-    hipLaunchKernelGGL(k_bn_finalize<1>, dim3(urn_cdiv(c, 16)), dim3(256), 0, st, part, nblk, (long)n, c, 0.0, dgamma,
+    hipLaunchKernelGGL(k_bn_finalize<1>, dim3(urn_cdiv(c, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, part, nblk, (long)n, c, 0.0, dgamma,
                        dbeta, coef, coef + c, 0.0);
     long total = (long)n * c;
     if (total > 0) {
@@ -340,6 +345,125 @@ extern "C" int urn_rows_scatter_add(const float *dy, const int32_t *idx, int64_t
     URN_CHECK_ARG(dy && idx && dx && c > 0, "bad argument");
     hipLaunchKernelGGL(k_rows_scatter_add, dim3(urn_cdiv(n * c, 256)), dim3(256), 0, (hipStream_t)stream, dy, idx,
                        (long)n, c, dx);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// ------------------------------------------------------------ fused BatchNorm pieces --
+// (see include/uresnet_hip.h: the partial sums come from the gather-conv epilogues)
+__global__ __launch_bounds__(1024) void k_bn_finalize_fwd_f(const double *__restrict__ part, int nblk, long n, int c,
+                                                           int ld, double eps, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float *__restrict__ mean,
+                                                           float *__restrict__ invstd, float *__restrict__ scale,
+                                                           float *__restrict__ shift, float *rm, float *rv,
+                                                           double momentum)
+{
+    __shared__ double s0[1024], s1[1024];
+    const int t = threadIdx.x, cl = t & 15, bg = t >> 4, G = blockDim.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    if (col < c) {
+        int b = bg;
+        for (; b + G < nblk; b += 2 * G) {   // two partials in flight per lane
+            a0 += part[((long)b * 2) * ld + col];
+            a1 += part[((long)b * 2 + 1) * ld + col];
+            b0 += part[((long)(b + G) * 2) * ld + col];
+            b1 += part[((long)(b + G) * 2 + 1) * ld + col];
+        }
+        if (b < nblk) { a0 += part[((long)b * 2) * ld + col]; a1 += part[((long)b * 2 + 1) * ld + col]; }
+    }
+    s0[t] = a0 + b0; s1[t] = a1 + b1;
+    __syncthreads();
+    if (t < 16 && col < c) {
+        double v0 = 0.0, v1 = 0.0;
+        for (int j = 0; j < G; ++j) { v0 += s0[j * 16 + t]; v1 += s1[j * 16 + t]; }
+        const double m = n > 0 ? v0 / (double)n : 0.0;
+        double v = n > 0 ? v1 / (double)n - m * m : 0.0;
+        if (v < 0.0) v = 0.0;
+        const double is = 1.0 / sqrt(v + eps);
+        mean[col] = (float)m;
+        invstd[col] = (float)is;
+        const float sc = gamma[col] * (float)is;
+        scale[col] = sc;
+        shift[col] = fmaf(-(float)m, sc, beta[col]);
+        if (rm) rm[col] = (float)(momentum * rm[col] + (1.0 - momentum) * m);
+        if (rv) rv[col] = (float)(momentum * rv[col] + (1.0 - momentum) * v);
+    }
+}
+
+__global__ void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ g,
+                               const float *__restrict__ extra, long total, int c,
+                               const float *__restrict__ gamma, const float *__restrict__ mean,
+                               const float *__restrict__ invstd, const float *__restrict__ c0,
+                               const float *__restrict__ c1, float *__restrict__ dx)
+{
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= total) return;  // c % 4 == 0
+    const int col = (int)(i % c);
+    const f32x4 xv = *(const f32x4 *)(x + i), gv = *(const f32x4 *)(g + i);
+    f32x4 ev = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (extra) ev = *(const f32x4 *)(extra + i);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float is = invstd[col + k];
+        const float xh = (xv[k] - mean[col + k]) * is;
+        o[k] = gamma[col + k] * is * (gv[k] - c0[col + k] - xh * c1[col + k]) + ev[k];
+    }
+    *(f32x4 *)(dx + i) = o;
+}
+
+extern "C" int urn_bn_stats_partial(const float *x, int64_t n, int c, double *part, int *n_part, void *stream)
+{
+    URN_CHECK_ARG(c > 0 && n >= 0 && part && n_part && (n == 0 || x), "bad argument");
+    if (!URN_BN_SHAPE_OK(c)) { urn_set_error("urn_bn_stats_partial: unsupported channel count %d", c); return URN_EUNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = bn_vec(c);
+    long rpb;
+    int nblk = bn_grid(n, c, vec, &rpb);
+    if (vec == 4)
+        hipLaunchKernelGGL((k_bn_partial<0, 4>), dim3(nblk), dim3(256), 0, st, x, (const float *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, (long)n, c, 0, rpb, part);
+    else
+        hipLaunchKernelGGL((k_bn_partial<0, 1>), dim3(nblk), dim3(256), 0, st, x, (const float *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, (long)n, c, 0, rpb, part);
+    *n_part = nblk;
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_bn_finalize_fwd(const double *part, int n_part, int64_t n, int c, int part_ld, double eps,
+                                   const float *gamma, const float *beta, float *mean, float *invstd, float *scale,
+                                   float *shift, float *running_mean, float *running_var, double momentum,
+                                   void *stream)
+{
+    URN_CHECK_ARG(part && n_part >= 0 && c > 0 && part_ld >= c && gamma && beta && mean && invstd && scale && shift, "bad argument");
+    hipLaunchKernelGGL(k_bn_finalize_fwd_f, dim3(urn_cdiv(c, 16)), dim3(n_part > 128 ? 1024 : 256), 0, (hipStream_t)stream, part, n_part, (long)n, c,
+                       part_ld, eps, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, momentum);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_bn_finalize_bwd(const double *part, int n_part, int64_t n, int c, float *dgamma, float *dbeta,
+                                   float *coef0, float *coef1, void *stream)
+{
+    URN_CHECK_ARG(part && n_part >= 0 && c > 0 && dgamma && dbeta && coef0 && coef1, "bad argument");
+    hipLaunchKernelGGL(k_bn_finalize<1>, dim3(urn_cdiv(c, 16)), dim3(n_part > 128 ? 1024 : 256), 0, (hipStream_t)stream, part, n_part, (long)n, c, 0.0,
+                       dgamma, dbeta, coef0, coef1, 0.0);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_bn_bwd_apply(const float *x, const float *g, const float *extra, int64_t n, int c,
+                                const float *gamma, const float *mean, const float *invstd, const float *coef0,
+                                const float *coef1, float *dx, void *stream)
+{
+    URN_CHECK_ARG(c > 0 && c % 4 == 0 && n >= 0 && gamma && mean && invstd && coef0 && coef1, "bad argument (c must be a multiple of 4)");
+    const long total = (long)n * c;
+    if (total == 0) return URN_OK;
+    URN_CHECK_ARG(x && g && dx, "null pointer");
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(urn_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, g, extra, total, c,
+                       gamma, mean, invstd, coef0, coef1, dx);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }

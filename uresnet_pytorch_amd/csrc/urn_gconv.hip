@@ -28,7 +28,8 @@
 #define DW_SLOTS 5    // ceil(4*5/4)
 #define DW_LIST 1024
 
-__global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, const float *__restrict__ dy,
+__global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, const float *__restrict__ xf_scale,
+                                                  const float *__restrict__ xf_shift, const float *__restrict__ dy,
                                                   const int *__restrict__ tbl, long ld, long n_out, int cin,
                                                   int cout, long chunk, int n_ci_tiles,
                                                   float *__restrict__ dw)
@@ -86,7 +87,15 @@ __global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, c
             for (int e = tid; e < DW_KT * (ci_w / 4); e += 256) {
                 int rr = e / (ci_w / 4), c4 = e - rr * (ci_w / 4);
                 f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rr < nb) v = *(const f32x4 *)(x + (long)s_in[done + rr] * cin + ci0 + 4 * c4);
+                if (rr < nb) {
+                    v = *(const f32x4 *)(x + (long)s_in[done + rr] * cin + ci0 + 4 * c4);
+                    if (xf_scale) {  // the conv's input was relu(x*scale + shift): recompute it on the fly
+                        const f32x4 sc = *(const f32x4 *)(xf_scale + ci0 + 4 * c4);
+                        const f32x4 sh = *(const f32x4 *)(xf_shift + ci0 + 4 * c4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
+                    }
+                }
                 *(f32x4 *)&s_a[rr][4 * c4] = v;
             }
             for (int e = tid; e < DW_KT * (co_w / 4); e += 256) {
@@ -158,11 +167,20 @@ __global__ void k_gconv_dw_small(const float *__restrict__ x, const float *__res
 extern "C" int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *tbl, int64_t ld, int K,
                                 int64_t n_out, int cin, int cout, float *dw, void *stream)
 {
+    return urn_gconv_bwd_dw_ex(x, nullptr, nullptr, dy, tbl, ld, K, n_out, cin, cout, dw, stream);
+}
+
+extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const float *xf_shift, const float *dy,
+                                   const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout,
+                                   float *dw, void *stream)
+{
     if (n_out <= 0) return URN_OK;
     URN_CHECK_ARG(x && dy && tbl && dw, "null pointer");
     URN_CHECK_ARG(K > 0 && cin > 0 && cout > 0 && ld >= n_out, "bad shape");
+    URN_CHECK_ARG((xf_scale == nullptr) == (xf_shift == nullptr), "scale and shift go together");
     hipStream_t st = (hipStream_t)stream;
     if ((cin % 16) || (cout % 16)) {
+        if (xf_scale) { urn_set_error("urn_gconv_bwd_dw_ex: input transform needs channel counts that are multiples of 16"); return URN_EUNSUPPORTED; }
         int chunks = (int)((n_out + 1023) / 1024);
         if (chunks > 128) chunks = 128;
         long chunk = (n_out + chunks - 1) / chunks;
@@ -181,7 +199,7 @@ extern "C" int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *
     chunks = (int)((n_out + chunk - 1) / chunk);
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_DW, st);
-    hipLaunchKernelGGL(k_gconv_dw, dim3(chunks, K, n_ci_tiles * n_co_tiles), dim3(256), 0, st, x, dy, tbl, (long)ld,
+    hipLaunchKernelGGL(k_gconv_dw, dim3(chunks, K, n_ci_tiles * n_co_tiles), dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,
                        (long)n_out, cin, cout, chunk, n_ci_tiles, dw);
     if (prof) urn_prof_end(st);
     URN_LAUNCH_CHECK();

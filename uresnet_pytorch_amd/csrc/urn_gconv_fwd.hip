@@ -2,123 +2,225 @@
 // scn.SubmanifoldConvolution, scn.Convolution(k2,s2), scn.Deconvolution(k2,s2) and
 // scn.NetworkInNetwork (reference call sites uresnet/models/uresnet_sparse.py:21-22).
 //
-//   y[j,:] = sum_{o<K} x[tbl[t(o)*ld + j], :] @ W[o]   (+ res[j,:])
+//   y[j,:] = sum_{o<K} T(x[tbl[t(o)*ld + j], :]) @ W[o]   (+ res[j,:])
 //
-// Output stationary, no atomics, bit-reproducible.  A workgroup owns one tile of 16
-// output rows x NB*16 output columns (SPLIT=4: its four waves share the tile and split
-// the ACTIVE filter offsets between them, partial tiles are summed through LDS in wave
-// order) or four such tiles (SPLIT=1: one per wave).  Per tile:
-//   1. all K table rows of the tile are fetched at once (7 coalesced loads per lane),
-//      wave64 ballots turn them into a bit mask of offsets that have any active
-//      neighbour; inactive offsets cost nothing;
-//   2. for each active offset the wave gathers its A operand straight from HBM/L2 in
-//      MFMA layout (16-byte loads: 4 k-values of one gathered row per lane) and the B
-//      operand from the pre-transposed, L2-resident weights (K, cout, cin); the k loop is
-//      fully unrolled (KS = cin/16 is a template parameter) so every load of an offset
-//      is in flight before the first v_mfma_f32_16x16x4_f32 issues.
+// Output stationary, no atomics, bit-reproducible.  A workgroup owns one tile of MB*16
+// output rows x NB*16 output columns (SPLIT=4: its four waves share the tile and split the
+// ACTIVE filter offsets between them, partial tiles are summed through LDS in wave order) or
+// four such tiles (SPLIT=1: one per wave).  Per tile:
+//   1. all K table rows of the tile are fetched at once (7 coalesced loads per lane and
+//      16-row block), wave64 ballots turn them into bit masks of the offsets that have any
+//      active neighbour; inactive offsets cost nothing;
+//   2. for each active offset the wave gathers its A operand straight from HBM/L2 in MFMA
+//      layout (16-byte loads: 4 k-values of one gathered row per lane) and the B operand from
+//      the pre-transposed, L2-resident weights (K, cout, cin); the k loop is fully unrolled
+//      (KS = cin/16 is a template parameter) so every load of an offset is in flight before
+//      the first v_mfma_f32_16x16x4_f32 issues;
+//   3. optional fusions that remove whole HBM passes of the surrounding BatchNorm+ReLU layers:
+//      T = relu(x*scale + shift) applied to the gathered rows (BatchNormReLU forward folded
+//      into the load), per-tile column sums / sums of squares of y in fp64 (the NEXT
+//      BatchNorm's statistics), or the BatchNorm backward reduction (sum g, sum g*xhat with
+//      the ReLU mask applied) when the kernel computes an input gradient.
 #include "urn_common.h"
 #include "urn_prof.h"
+#include "urn_gconv_int.h"
+#include <string.h>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int KS, int NB, int SPLIT>
-__global__ __launch_bounds__(256) void k_gconv_fwd(const float *__restrict__ x, const float *__restrict__ wt,
-                                                   const int *__restrict__ tbl, long ld, int K, int flip,
-                                                   const int *n_dev, long n_cap, int cout,
-                                                   const float *__restrict__ res, float *__restrict__ y)
+template <int KS, int MB, int NB, int SPLIT, int PIPE>
+__global__ __launch_bounds__(256) void k_gconv_fwd(GArgs g)
 {
     constexpr int CIN = KS * 16;
-    __shared__ int s_idx[4][28 * 16];
-    __shared__ f32x4 s_red[SPLIT == 4 ? 4 * NB * 64 : 1];
+    __shared__ int s_idx[4][MB][28 * 16];
+    __shared__ f32x4 s_red[SPLIT == 4 ? 4 * MB * NB * 64 : 1];
 
-    const long n_out = n_dev ? (long)*n_dev : n_cap;
+    const long n_out = g.n_dev ? (long)*g.n_dev : g.n_cap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     const long tile = (SPLIT == 4) ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
-    const long row_base = tile * 16;
+    const long row_base = tile * (MB * 16);
     if (SPLIT == 1 && row_base >= n_out) return;  // wave-uniform, no barriers in this variant
     const bool tile_ok = row_base < n_out;         // block-uniform when SPLIT == 4
     const int col_base = blockIdx.y * (NB * 16);
+    const int K = g.K, cout = g.cout;
 
-    // 1. the tile's table: lane (r, q) fetches table rows q, q+4, ... for output row r
-    unsigned amask = 0u;
-    {
-        const long row = row_base + r;
+    // 1. the tile's table: lane (r, q) fetches table rows q, q+4, ... for its output row of every block
+    unsigned amask[MB], any_mask = 0u;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        amask[mb] = 0u;
+        const long row = row_base + mb * 16 + r;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int t = 4 * i + q;
             int v = -1;
-            if (t < K && row < n_out) v = tbl[(long)t * ld + row];
-            s_idx[wave][i * 64 + lane] = v;  // == [t][r]
+            if (t < K && row < n_out) v = g.tbl[(long)t * g.ld + row];
+            s_idx[wave][mb][i * 64 + lane] = v;  // == [t][r]
             const unsigned long long b = __ballot(v >= 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if ((b >> (16 * j)) & 0xFFFFull) amask |= 1u << (4 * i + j);
+                if ((b >> (16 * j)) & 0xFFFFull) amask[mb] |= 1u << (4 * i + j);
         }
+        any_mask |= amask[mb];
     }
 
-    f32x4 acc[NB];
+    f32x4 acc[MB][NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // 2. active offsets (table rows), split round-robin between the waves when SPLIT == 4
+    const bool xf = g.xf_scale != nullptr;
+
+    // 2. active offsets (table rows), split round-robin between the waves when SPLIT == 4.
+    //    Software-pipelined: the operands of the NEXT active offset are in flight while the MFMAs of the
+    //    current one issue (two named register sets, ping-pong, no moves).
     int cnt = 0;
-    unsigned m = amask;
-    while (m) {
-        const int t = __builtin_ctz(m);
-        m &= m - 1u;
-        if (SPLIT == 4 && ((cnt++ & 3) != wave)) continue;
-        const int o = flip ? (K - 1 - t) : t;  // weight index
-        const int idx = s_idx[wave][t * 16 + r];
-        const float *xa = x + (long)(idx < 0 ? 0 : idx) * CIN + 4 * q;
-        const float *wo = wt + ((long)o * cout + col_base + r) * CIN + 4 * q;
-        f32x4 a[KS], b[KS][NB];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            a[ks] = *(const f32x4 *)(xa + ks * 16);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[ks][nb] = *(const f32x4 *)(wo + (long)nb * 16 * CIN + ks * 16);
+    unsigned m = any_mask;
+    auto next_active = [&]() -> int {
+        while (m) {
+            const int t = __builtin_ctz(m);
+            m &= m - 1u;
+            if (SPLIT == 4 && ((cnt++ & 3) != wave)) continue;
+            return t;
         }
-        if (idx < 0) {
+        return -1;
+    };
+    struct Ops { f32x4 a[MB][KS]; f32x4 b[KS][NB]; int idx[MB]; };
+    auto load_ops = [&](Ops &p, int t) {
+        const int o = g.flip ? (K - 1 - t) : t;  // weight index
+        const float *wo = g.wt + ((long)o * cout + col_base + r) * CIN + 4 * q;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[ks] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mb = 0; mb < MB; ++mb) {
+            p.idx[mb] = s_idx[wave][mb][t * 16 + r];
+            const float *xa = g.x + (long)(p.idx[mb] < 0 ? 0 : p.idx[mb]) * CIN + 4 * q;
+            if ((amask[mb] >> t) & 1u) {  // wave-uniform
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) p.a[mb][ks] = *(const f32x4 *)(xa + ks * 16);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
+            for (int nb = 0; nb < NB; ++nb) p.b[ks][nb] = *(const f32x4 *)(wo + (long)nb * 16 * CIN + ks * 16);
+    };
+    auto compute = [&](Ops &p, int t) {
+        if (xf) {  // BatchNormReLU folded into the load: u = relu(x*scale + shift)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA16(a[ks][tt], b[ks][nb][tt], acc[nb]);
+            for (int ks = 0; ks < KS; ++ks) {
+                const f32x4 sc = *(const f32x4 *)(g.xf_scale + ks * 16 + 4 * q);
+                const f32x4 sh = *(const f32x4 *)(g.xf_shift + ks * 16 + 4 * q);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    if ((amask[mb] >> t) & 1u) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p.a[mb][ks][e] = fmaxf(fmaf(p.a[mb][ks][e], sc[e], sh[e]), 0.f);
+                    }
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            if (!((amask[mb] >> t) & 1u)) continue;  // wave-uniform
+            if (p.idx[mb] < 0) {                     // a missing neighbour contributes zero, not T(0)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) p.a[mb][ks] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = MFMA16(p.a[mb][ks][tt], p.b[ks][nb][tt], acc[mb][nb]);
+        }
+    };
+    if (PIPE) {
+        Ops pa, pb;
+        int ta = next_active(), tb = -1;
+        if (ta >= 0) load_ops(pa, ta);
+        while (ta >= 0) {
+            tb = next_active();
+            if (tb >= 0) load_ops(pb, tb);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(pa, ta);
+            if (tb < 0) break;
+            ta = next_active();
+            if (ta >= 0) load_ops(pa, ta);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(pb, tb);
+        }
+    } else {
+        Ops pa;
+        for (int ta = next_active(); ta >= 0; ta = next_active()) {
+            load_ops(pa, ta);
+            compute(pa, ta);
+        }
     }
 
     // 3. (SPLIT == 4) sum the four partial tiles in wave order
     if (SPLIT == 4) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) s_red[(wave * NB + nb) * 64 + lane] = acc[nb];
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) s_red[((wave * MB + mb) * NB + nb) * 64 + lane] = acc[mb][nb];
         __syncthreads();
         if (wave != 0 || !tile_ok) return;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            f32x4 s = s_red[(0 * NB + nb) * 64 + lane];
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                f32x4 p = s_red[(w * NB + nb) * 64 + lane];
-                s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x4 s = s_red[((0 * MB + mb) * NB + nb) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const f32x4 p = s_red[((w * MB + mb) * NB + nb) * 64 + lane];
+                    s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];
+                }
+                acc[mb][nb] = s;
             }
-            acc[nb] = s;
-        }
     }
-    // C layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+
+    // 4. epilogue.  C layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+    double s0[NB], s1[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long row = row_base + q * 4 + i;
-        if (row >= n_out) continue;
+    for (int nb = 0; nb < NB; ++nb) { s0[nb] = 0.0; s1[nb] = 0.0; }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = col_base + nb * 16 + r;
+        float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
+        if (g.epi == 2) { esc = g.e_scale[col]; esh = g.e_shift[col]; emu = g.e_mean[col]; eis = g.e_invstd[col]; }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long row = row_base + mb * 16 + q * 4 + i;
+                if (row >= n_out) continue;
+                const long off = row * cout + col;
+                float v = acc[mb][nb][i];
+                if (g.res) v += g.res[off];
+                if (g.epi == 1) {
+                    s0[nb] += (double)v;
+                    s1[nb] += (double)v * (double)v;
+                } else if (g.epi == 2) {
+                    const float xv = g.e_x[off];
+                    if (!(fmaf(xv, esc, esh) > 0.f)) v = 0.f;             // ReLU mask of the forward
+                    const double xh = ((double)xv - (double)emu) * (double)eis;
+                    s0[nb] += (double)v;
+                    s1[nb] += (double)v * xh;
+                }
+                g.y[off] = v;
+            }
+    }
+    if (g.epi != 0) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const long off = row * cout + col_base + nb * 16 + r;
-            float v = acc[nb][i];
-            if (res) v += res[off];
-            y[off] = v;
+            double a0 = s0[nb], a1 = s1[nb];
+            a0 += __shfl_xor(a0, 16); a1 += __shfl_xor(a1, 16);
+            a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
+            if (q == 0) {
+                const int col = col_base + nb * 16 + r;
+                g.part[(tile * 2 + 0) * cout + col] = a0;
+                g.part[(tile * 2 + 1) * cout + col] = a1;
+            }
         }
     }
 }
@@ -145,88 +247,130 @@ __global__ void k_gconv_small(const float *__restrict__ x, const float *__restri
     y[t] = acc;
 }
 
-struct FwdArgs {
-    const float *x, *wt;
-    const int *tbl;
-    long ld;
-    int K, flip;
-    long n_out;
-    int cout;
-    const float *res;
-    float *y;
-    hipStream_t st;
-};
+struct Pick { int mb, nb; };
 
-template <int KS, int NB>
-static void launch_ks_nb(const FwdArgs &a, bool split)
+// tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
+// before the column tile is widened
+static int g_opt_pipe = 0;
+static int g_opt_kernel = 4;   // 4 = LDS-staged tile kernel (urn_gconv_lds.hip), 3 = register-gather kernel below
+static long g_opt_min_waves = 8192;
+
+extern "C" int urn_set_option(const char *key, int64_t value)
 {
-    const long tiles = (a.n_out + 15) / 16;
+    URN_CHECK_ARG(key, "null key");
+    if (!strcmp(key, "gconv_pipe")) { g_opt_pipe = value != 0; return URN_OK; }
+    if (!strcmp(key, "gconv_min_waves")) { g_opt_min_waves = value; return URN_OK; }
+    if (!strcmp(key, "gconv_kernel")) { g_opt_kernel = (int)value; return URN_OK; }
+    urn_set_error("urn_set_option: unknown key %s", key);
+    return URN_EINVAL;
+}
+
+// Tile shape.  Measured on MI355X: these kernels are bound by the per-wave latency chain (table fetch ->
+// gather -> MFMA), so more, smaller waves win over wider register tiles; columns are widened (fewer
+// re-gathers of the A rows) only while the launch keeps >= 8 waves per SIMD.
+static Pick pick_tile(int ks, int nblk, long n_out, bool split)
+{
+    const long tiles = (n_out + 15) / 16;
+    for (int nb = 5; nb >= 2; --nb) {
+        if (nblk % nb) continue;
+        if (2 * (4 * ks * (1 + nb)) + 4 * nb > 200) continue;   // two operand sets (software pipeline)
+        if (tiles * (split ? 4 : 1) * (nblk / nb) >= g_opt_min_waves) return Pick{1, nb};
+    }
+    return Pick{1, 1};
+}
+
+template <int KS, int MB, int NB>
+static void launch_tile(const GArgs &a, long n_out, bool split, hipStream_t st)
+{
+    const long tiles = (n_out + MB * 16 - 1) / (MB * 16);
     const int gy = a.cout / (NB * 16);
-    if (split)
-        hipLaunchKernelGGL((k_gconv_fwd<KS, NB, 4>), dim3((unsigned)tiles, gy), dim3(256), 0, a.st, a.x, a.wt, a.tbl,
-                           a.ld, a.K, a.flip, (const int *)nullptr, a.n_out, a.cout, a.res, a.y);
+    if (split && g_opt_pipe)
+        hipLaunchKernelGGL((k_gconv_fwd<KS, MB, NB, 4, 1>), dim3((unsigned)tiles, gy), dim3(256), 0, st, a);
+    else if (split)
+        hipLaunchKernelGGL((k_gconv_fwd<KS, MB, NB, 4, 0>), dim3((unsigned)tiles, gy), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((k_gconv_fwd<KS, NB, 1>), dim3((unsigned)((tiles + 3) / 4), gy), dim3(256), 0, a.st, a.x,
-                           a.wt, a.tbl, a.ld, a.K, a.flip, (const int *)nullptr, a.n_out, a.cout, a.res, a.y);
+        hipLaunchKernelGGL((k_gconv_fwd<KS, MB, NB, 1, 0>), dim3((unsigned)((tiles + 3) / 4), gy), dim3(256), 0, st, a);
 }
 
 template <int KS>
-static void launch_ks(const FwdArgs &a, int nb, bool split)
+static bool launch_ks(const GArgs &a, long n_out, Pick p, bool split, hipStream_t st)
 {
-    // operand registers: 4*KS*(1+NB); keep them under the 256-register budget
-    if (nb == 1) { launch_ks_nb<KS, 1>(a, split); return; }
-    if (nb == 2) { launch_ks_nb<KS, 2>(a, split); return; }
-    if constexpr (KS <= 8) {
-        if (nb == 3) { launch_ks_nb<KS, 3>(a, split); return; }
-        if (nb == 4) { launch_ks_nb<KS, 4>(a, split); return; }
+#define URN_T(MBv, NBv)                                                     \
+    if (p.mb == MBv && p.nb == NBv) {                                       \
+        if constexpr (8 * KS * (MBv + NBv) + 4 * MBv * NBv <= 200) {        \
+            launch_tile<KS, MBv, NBv>(a, n_out, split, st);                 \
+            return true;                                                    \
+        }                                                                   \
     }
-    if constexpr (KS <= 5) {
-        if (nb == 5) { launch_ks_nb<KS, 5>(a, split); return; }
+    URN_T(1, 1) URN_T(1, 2) URN_T(1, 3) URN_T(1, 4) URN_T(1, 5)
+#undef URN_T
+    return false;
+}
+
+extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *stream)
+{
+    URN_CHECK_ARG(u, "null args");
+    if (n_tiles) *n_tiles = 0;
+    if (u->n_out <= 0) return URN_OK;
+    URN_CHECK_ARG(u->x && u->wt && u->tbl && u->y, "null pointer");
+    URN_CHECK_ARG(u->K > 0 && u->cin > 0 && u->cout > 0 && u->ld >= u->n_out, "bad shape");
+    URN_CHECK_ARG((const void *)u->x != (const void *)u->y, "y aliases x");
+    URN_CHECK_ARG(u->epilogue == 0 || u->part, "epilogue needs a partial slab");
+    URN_CHECK_ARG(u->epilogue != 2 || (u->e_x && u->e_scale && u->e_shift && u->e_mean && u->e_invstd), "epilogue 2 needs the BatchNorm inputs");
+    hipStream_t st = (hipStream_t)stream;
+    const int ks = u->cin / 16;
+    const bool mfma_ok = (u->cin % 16 == 0) && (u->cout % 16 == 0) && u->K <= 28 &&
+                         (ks <= 6 || ks == 8 || ks == 10 || ks == 12 || ks == 14);
+    if (!mfma_ok) {
+        if (u->xf_scale || u->epilogue) { urn_set_error("urn_gconv_fwd_ex: fusions need channel counts that are multiples of 16"); return URN_EUNSUPPORTED; }
+        hipLaunchKernelGGL(k_gconv_small, dim3(urn_cdiv(u->n_out * u->cout, 256)), dim3(256), 0, st, u->x, u->wt, u->tbl,
+                           (long)u->ld, u->K, u->flip, (long)u->n_out, u->cin, u->cout, u->res, u->y);
+        URN_LAUNCH_CHECK();
+        return URN_OK;
     }
+    const bool split = u->K >= 8;
+    const Pick p = pick_tile(ks, u->cout / 16, u->n_out, split);
+    GArgs a{u->x, u->wt, u->tbl, (long)u->ld, u->K, u->flip, nullptr, (long)u->n_out, u->cout, u->res, u->y,
+            u->xf_scale, u->xf_shift, u->epilogue, u->part, u->e_x, u->e_scale, u->e_shift, u->e_mean, u->e_invstd};
+    const bool prof = urn_prof_on();
+    if (prof) urn_prof_begin(URN_PROF_GCONV, st);
+    bool ok = false;
+    if (g_opt_kernel == 4 && urn_gconv_lds_launch(a, ks, u->n_out, st)) {
+        if (prof) urn_prof_end(st);
+        if (n_tiles) *n_tiles = (int)((u->n_out + 15) / 16);
+        URN_LAUNCH_CHECK();
+        return URN_OK;
+    }
+    switch (ks) {
+    case 1: ok = launch_ks<1>(a, u->n_out, p, split, st); break;
+    case 2: ok = launch_ks<2>(a, u->n_out, p, split, st); break;
+    case 3: ok = launch_ks<3>(a, u->n_out, p, split, st); break;
+    case 4: ok = launch_ks<4>(a, u->n_out, p, split, st); break;
+    case 5: ok = launch_ks<5>(a, u->n_out, p, split, st); break;
+    case 6: ok = launch_ks<6>(a, u->n_out, p, split, st); break;
+    case 8: ok = launch_ks<8>(a, u->n_out, p, split, st); break;
+    case 10: ok = launch_ks<10>(a, u->n_out, p, split, st); break;
+    case 12: ok = launch_ks<12>(a, u->n_out, p, split, st); break;
+    default: ok = launch_ks<14>(a, u->n_out, p, split, st); break;
+    }
+    if (prof) urn_prof_end(st);
+    if (!ok) { urn_set_error("urn_gconv_fwd_ex: no kernel for cin=%d tile %dx%d", u->cin, p.mb, p.nb); return URN_EUNSUPPORTED; }
+    if (n_tiles) *n_tiles = (int)((u->n_out + p.mb * 16 - 1) / (p.mb * 16));
+    URN_LAUNCH_CHECK();
+    return URN_OK;
 }
 
 extern "C" int urn_gconv_fwd(const float *x, const float *wt, const int32_t *tbl, int64_t ld, int K, int flip,
                              int64_t n_out, int cin, int cout, const float *res, float *y, void *stream)
 {
-    if (n_out <= 0) return URN_OK;
-    URN_CHECK_ARG(x && wt && tbl && y, "null pointer");
-    URN_CHECK_ARG(K > 0 && cin > 0 && cout > 0 && ld >= n_out, "bad shape");
-    URN_CHECK_ARG((const void *)x != (const void *)y, "y aliases x");
-    hipStream_t st = (hipStream_t)stream;
-    const int ks = cin / 16;
-    const bool mfma_ok = (cin % 16 == 0) && (cout % 16 == 0) && K <= 28 &&
-                         (ks <= 6 || ks == 8 || ks == 10 || ks == 12 || ks == 14);
-    if (!mfma_ok) {
-        hipLaunchKernelGGL(k_gconv_small, dim3(urn_cdiv(n_out * cout, 256)), dim3(256), 0, st, x, wt, tbl, (long)ld,
-                           K, flip, (long)n_out, cin, cout, res, y);
-        URN_LAUNCH_CHECK();
-        return URN_OK;
-    }
-    const int nblk = cout / 16;
-    // columns per wave: the largest divisor of cout/16 that keeps the operand registers under budget
-    const int nb_max = ks <= 5 ? 5 : (ks <= 8 ? 4 : 2);
-    const bool split = K >= 8;
-    // ... and that still leaves >= ~4 waves per SIMD (1024 SIMDs) to hide the gather latency
-    const long tiles16 = (n_out + 15) / 16;
-    int nb = 1;
-    for (int d = nb_max; d >= 1; --d)
-        if (nblk % d == 0 && (d == 1 || tiles16 * (split ? 4 : 1) * (nblk / d) >= 4096)) { nb = d; break; }
-    FwdArgs a{x, wt, tbl, (long)ld, K, flip, (long)n_out, cout, res, y, st};
-    const bool prof = urn_prof_on();
-    if (prof) urn_prof_begin(URN_PROF_GCONV, st);
-    switch (ks) {
-    case 1: launch_ks<1>(a, nb, split); break;
-    case 2: launch_ks<2>(a, nb, split); break;
-    case 3: launch_ks<3>(a, nb, split); break;
-    case 4: launch_ks<4>(a, nb, split); break;
-    case 5: launch_ks<5>(a, nb, split); break;
-    case 6: launch_ks<6>(a, nb, split); break;
-    case 8: launch_ks<8>(a, nb, split); break;
-    case 10: launch_ks<10>(a, nb > 2 ? 2 : nb, split); break;
-    case 12: launch_ks<12>(a, nb > 2 ? 2 : nb, split); break;
-    default: launch_ks<14>(a, nb > 2 ? 2 : nb, split); break;
-    }
-    if (prof) urn_prof_end(st);
-    URN_LAUNCH_CHECK();
-    return URN_OK;
+    urn_gconv_args u;
+    memset(&u, 0, sizeof(u));
+    u.x = x; u.wt = wt; u.tbl = tbl; u.ld = ld; u.K = K; u.flip = flip; u.n_out = n_out; u.cin = cin; u.cout = cout;
+    u.res = res; u.y = y;
+    return urn_gconv_fwd_ex(&u, nullptr, stream);
+}
+
+extern "C" int64_t urn_gconv_part_bytes(int64_t n_out, int cout)
+{
+    return ((n_out + 15) / 16) * 2 * (int64_t)cout * 8 + 256;
 }

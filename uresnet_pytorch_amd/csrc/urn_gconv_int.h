@@ -1,0 +1,22 @@
+// Internal launch record shared by the gather-conv kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct GArgs {
+    const float *x, *wt;
+    const int *tbl;
+    long ld;
+    int K, flip;
+    const int *n_dev;
+    long n_cap;
+    int cout;
+    const float *res;
+    float *y;
+    const float *xf_scale, *xf_shift;
+    int epi;
+    double *part;
+    const float *e_x, *e_scale, *e_shift, *e_mean, *e_invstd;
+};
+
+// LDS-staged variant (urn_gconv_lds.hip): returns false when it has no instantiation for the shape
+bool urn_gconv_lds_launch(const GArgs &a, int ks, long n_out, hipStream_t st);

@@ -11,6 +11,7 @@
 // all-reduce per step consumes.
 #include "urn_common.h"
 #include <algorithm>
+#include <string.h>
 #include <memory>
 #include <vector>
 
@@ -46,7 +47,17 @@ struct Geo {
 };
 
 struct ConvP { int64_t w; int K, cin, cout; const float *x = nullptr; };           // saved input
-struct BNP { int64_t w, b, run; int c; const float *x = nullptr, *y = nullptr; float *mean = nullptr, *invstd = nullptr; };
+struct BNP {
+    int64_t w, b, run; int c;
+    const float *x = nullptr, *y = nullptr;
+    float *mean = nullptr, *invstd = nullptr;
+    float *scale = nullptr, *shift = nullptr;   // fused path: relu(x*scale + shift) == BatchNormReLU(x)
+};
+// column partials (sum, sum of squares; fp64) of a tensor, written by its producer's epilogue
+struct Stats { double *part = nullptr; int n_part = 0, ld = 0; };
+// an activation tensor of the fused path: rows, channels and where its statistics come from;
+// a channel concat carries two slabs (columns [0,c0) from st, [c0,c) from st2)
+struct Act { float *x = nullptr; int64_t n = 0; int c = 0; Stats st, st2; int c0 = 0; };
 struct Block { bool has_nin; ConvP nin; BNP bn1; ConvP conv1; BNP bn2; ConvP conv2; };
 struct ULevel {
     std::vector<Block> pre, post;
@@ -249,6 +260,150 @@ struct urn_net {
         for (int i = (int)lv.pre.size() - 1; i >= 0; --i) dy = block_bwd(lv.pre[i], dy, l);
         return dy;
     }
+
+    // ==== fused path: BatchNorm+ReLU folded into the gather convolutions =================
+    // forward : producer conv writes column partials [epilogue 1] -> bn_finalize -> consumer conv
+    //           applies relu(x*scale+shift) on load; the normalised tensor is never written.
+    // backward: dX conv masks with the ReLU and reduces (sum g, sum g*xhat) [epilogue 2] ->
+    //           finalize (dgamma, dbeta, coefficients) -> apply (+ residual-branch gradient).
+    int fused = 1;
+
+    Act conv_f(ConvP &c, const Act &in, const BNP *xf, const int32_t *tbl, int64_t n_out, const float *res, bool stats)
+    {
+        c.x = in.x;
+        Act y;
+        y.n = n_out; y.c = c.cout;
+        y.x = arena.f32(n_out * c.cout);
+        const bool mfma = (c.cin % 16 == 0) && (c.cout % 16 == 0);
+        if (stats) {
+            y.st.ld = c.cout;
+            y.st.part = (double *)arena.alloc_bytes(mfma ? (size_t)urn_gconv_part_bytes(n_out, c.cout)
+                                                          : (size_t)urn_bn_scratch_bytes(c.cout));
+        }
+        if (live()) {
+            urn_gconv_args a;
+            memset(&a, 0, sizeof(a));
+            a.x = in.x; a.wt = wt_all + c.w; a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
+            a.cin = c.cin; a.cout = c.cout; a.res = res; a.y = y.x;
+            if (xf) { a.xf_scale = xf->scale; a.xf_shift = xf->shift; }
+            if (stats && mfma) { a.epilogue = 1; a.part = y.st.part; }
+            check(urn_gconv_fwd_ex(&a, &y.st.n_part, st));
+            if (stats && !mfma) check(urn_bn_stats_partial(y.x, n_out, c.cout, y.st.part, &y.st.n_part, st));
+        }
+        return y;
+    }
+    void bn_finalize(BNP &b, const Act &in)
+    {
+        b.x = in.x;
+        b.mean = arena.f32(b.c); b.invstd = arena.f32(b.c); b.scale = arena.f32(b.c); b.shift = arena.f32(b.c);
+        if (!live()) return;
+        float *rm = running ? running + b.run : nullptr;
+        float *rv = running ? running + b.run + b.c : nullptr;
+        const int c0 = in.st2.part ? in.c0 : b.c;
+        check(urn_bn_finalize_fwd(in.st.part, in.st.n_part, in.n, c0, in.st.ld, eps, params + b.w, params + b.b, b.mean,
+                                  b.invstd, b.scale, b.shift, rm, rv, momentum, st));
+        if (in.st2.part)
+            check(urn_bn_finalize_fwd(in.st2.part, in.st2.n_part, in.n, b.c - c0, in.st2.ld, eps, params + b.w + c0,
+                                      params + b.b + c0, b.mean + c0, b.invstd + c0, b.scale + c0, b.shift + c0,
+                                      rm ? rm + c0 : nullptr, rv ? rv + c0 : nullptr, momentum, st));
+    }
+    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out)
+    {
+        hipStream_t ws = st;
+        if (side && !events.empty()) {
+            hipEvent_t e = events[ev_next++ % events.size()];
+            if (hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess) {
+                ws = side;
+                side_used = true;
+            }
+        }
+        check(urn_gconv_bwd_dw_ex(c.x, xf ? xf->scale : nullptr, xf ? xf->shift : nullptr, dy, tbl_f, geo.ld, c.K, n_out,
+                                  c.cin, c.cout, grads + c.w, ws));
+    }
+    // backward of conv(BNReLU_b(x)): returns d/dx (raw input of the BatchNorm), adds `extra` when given
+    float *conv_b_fused(ConvP &c, BNP &b, const float *dy, const int32_t *tbl_f, const int32_t *tbl_b, int flip_b,
+                        int64_t n_out, int64_t n_in, const float *extra)
+    {
+        float *g = arena.f32(n_in * c.cin);
+        double *part = (double *)arena.alloc_bytes((size_t)urn_gconv_part_bytes(n_in, c.cin));
+        float *coef = arena.f32(2 * (int64_t)c.cin);
+        float *dx = arena.f32(n_in * c.cin);
+        if (live()) {
+            dw_launch(c, &b, dy, tbl_f, n_out);
+            urn_gconv_args a;
+            memset(&a, 0, sizeof(a));
+            a.x = dy; a.wt = params + c.w; a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
+            a.cin = c.cout; a.cout = c.cin; a.y = g;
+            a.epilogue = 2; a.part = part;
+            a.e_x = b.x; a.e_scale = b.scale; a.e_shift = b.shift; a.e_mean = b.mean; a.e_invstd = b.invstd;
+            int n_part = 0;
+            check(urn_gconv_fwd_ex(&a, &n_part, st));
+            check(urn_bn_finalize_bwd(part, n_part, n_in, c.cin, grads + b.w, grads + b.b, coef, coef + c.cin, st));
+            check(urn_bn_bwd_apply(b.x, g, extra, n_in, c.cin, params + b.w, b.mean, b.invstd, coef, coef + c.cin, dx, st));
+        }
+        return dx;
+    }
+    Act block_f(Block &k, const Act &x, int l)
+    {
+        const int64_t n = geo.n[l];
+        const int32_t *nbr = geo.nbr[l];
+        const float *sc = x.x;
+        if (k.has_nin) sc = conv_f(k.nin, x, nullptr, nbr + 13 * geo.ld, n, nullptr, false).x;
+        bn_finalize(k.bn1, x);
+        Act t = conv_f(k.conv1, x, &k.bn1, nbr, n, nullptr, true);
+        bn_finalize(k.bn2, t);
+        return conv_f(k.conv2, t, &k.bn2, nbr, n, sc, true);
+    }
+    Act u_f(ULevel &lv, Act x, int l)
+    {
+        for (auto &k : lv.pre) x = block_f(k, x, l);
+        if (lv.has_sub) {
+            const int64_t n = geo.n[l], nc_ = geo.n[l + 1];
+            const int P = planes[l];
+            bn_finalize(lv.bn_d, x);
+            Act t = conv_f(lv.down, x, &lv.bn_d, geo.chd[l], nc_, nullptr, true);
+            t = u_f(*lv.sub, t, l + 1);
+            bn_finalize(lv.bn_u, t);
+            Act z = conv_f(lv.up, t, &lv.bn_u, geo.up[l], n, nullptr, true);
+            Act cat;
+            cat.n = n; cat.c = 2 * P; cat.c0 = P; cat.st = x.st; cat.st2 = z.st;
+            cat.x = arena.f32(n * 2 * P);
+            if (live()) {
+                check(hipMemcpy2DAsync(cat.x, 2 * P * 4, x.x, P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
+                check(hipMemcpy2DAsync(cat.x + P, 2 * P * 4, z.x, P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
+            }
+            x = cat;
+            for (auto &k : lv.post) x = block_f(k, x, l);
+        }
+        return x;
+    }
+    float *block_b(Block &k, const float *dy, int l)
+    {
+        const int64_t n = geo.n[l];
+        const int32_t *nbr = geo.nbr[l];
+        const float *dsc = dy;
+        if (k.has_nin) dsc = conv_bwd(k.nin, dy, nbr + 13 * geo.ld, nbr + 13 * geo.ld, 0, n, n, true);
+        float *d = conv_b_fused(k.conv2, k.bn2, dy, nbr, nbr, 1, n, n, nullptr);
+        return conv_b_fused(k.conv1, k.bn1, d, nbr, nbr, 1, n, n, dsc);   // + gradient of the shortcut branch
+    }
+    float *u_b(ULevel &lv, float *dy, int l)
+    {
+        if (lv.has_sub) {
+            const int64_t n = geo.n[l], nc_ = geo.n[l + 1];
+            const int P = planes[l];
+            for (int i = (int)lv.post.size() - 1; i >= 0; --i) dy = block_b(lv.post[i], dy, l);
+            float *dskip = arena.f32(n * P), *dz = arena.f32(n * P);
+            if (live()) {
+                check(hipMemcpy2DAsync(dskip, P * 4, dy, 2 * P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
+                check(hipMemcpy2DAsync(dz, P * 4, dy + P, 2 * P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
+            }
+            float *d = conv_b_fused(lv.up, lv.bn_u, dz, geo.up[l], geo.chd[l], 0, n, nc_, nullptr);
+            d = u_b(*lv.sub, d, l + 1);
+            dy = conv_b_fused(lv.down, lv.bn_d, d, geo.chd[l], geo.up[l], 0, nc_, n, dskip);   // + skip-path gradient
+        }
+        for (int i = (int)lv.pre.size() - 1; i >= 0; --i) dy = block_b(lv.pre[i], dy, l);
+        return dy;
+    }
 };
 
 __global__ void k_add2(const float *__restrict__ a, const float *__restrict__ b, long n, float *__restrict__ o)
@@ -269,10 +424,12 @@ float *urn_net::add_into_new(const float *a, const float *b, int64_t count)
     return o;
 }
 
-extern "C" int urn_net_create(int m, int num_levels, int reps, int num_class, double eps, double momentum, urn_net **out)
+extern "C" int urn_net_create(int m, int num_levels, int reps, int num_class, double eps, double momentum, int flags,
+                              urn_net **out)
 {
     URN_CHECK_ARG(out && m > 0 && m % 16 == 0 && num_levels >= 1 && reps >= 1 && num_class > 0, "bad configuration (m must be a multiple of 16)");
     urn_net *n = new urn_net();
+    n->fused = (flags & URN_NET_UNFUSED) ? 0 : 1;
     n->m = m; n->L = num_levels; n->reps = reps; n->nc = num_class; n->eps = eps; n->momentum = momentum;
     for (int i = 1; i <= num_levels; ++i) n->planes.push_back(i * m);
     n->stem = n->make_conv(27, 1, m);
@@ -280,7 +437,7 @@ extern "C" int urn_net_create(int m, int num_levels, int reps, int num_class, do
     n->bn_out = n->make_bn(m);
     // side stream + a ring of events for the fork/join of the weight-gradient kernels; if the runtime is not
     // available (no GPU: build check, workspace sizing) the executor stays single-stream
-    if (hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking) == hipSuccess) {
+    if (!(flags & URN_NET_SINGLE_STREAM) && hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking) == hipSuccess) {
         for (int i = 0; i < 128; ++i) {
             hipEvent_t e;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
@@ -375,9 +532,25 @@ static int set_geo(urn_net *net, int num_levels, int64_t ld, const int64_t *n, c
 static void run_forward(urn_net *net, const float *site_feats)
 {
     transpose_all(net);
-    float *x = net->conv_fwd(net->stem, site_feats, net->geo.nbr[0], net->geo.n[0], nullptr);
+    const int64_t n0 = net->geo.n[0];
+    if (net->fused) {
+        Act f;
+        f.x = const_cast<float *>(site_feats); f.n = n0; f.c = 1;
+        Act x = net->conv_f(net->stem, f, nullptr, net->geo.nbr[0], n0, nullptr, true);
+        x = net->u_f(net->u, x, 0);
+        // the last BatchNormReLU feeds the OutputLayer, not a conv: materialise it
+        BNP &b = net->bn_out;
+        net->bn_finalize(b, x);
+        float *y = net->arena.f32(n0 * b.c);
+        b.y = y;
+        if (net->live())
+            net->check(urn_bn_relu_apply(x.x, n0, b.c, net->params + b.w, net->params + b.b, b.mean, b.invstd, 1, y, net->st));
+        net->trunk_out = y;
+        return;
+    }
+    float *x = net->conv_fwd(net->stem, site_feats, net->geo.nbr[0], n0, nullptr);
     x = net->u_fwd(net->u, x, 0);
-    net->trunk_out = net->bn_fwd(net->bn_out, x, net->geo.n[0]);
+    net->trunk_out = net->bn_fwd(net->bn_out, x, n0);
 }
 
 static void run_backward(urn_net *net, const float *d_rows)
@@ -390,7 +563,7 @@ static void run_backward(urn_net *net, const float *d_rows)
         net->check(urn_rows_scatter_add(d_rows, net->geo.row2site, net->geo.n_rows, net->m, d, net->st));
     }
     d = net->bn_bwd(net->bn_out, d, n0);
-    d = net->u_bwd(net->u, d, 0);
+    d = net->fused ? net->u_b(net->u, d, 0) : net->u_bwd(net->u, d, 0);
     net->conv_bwd(net->stem, d, net->geo.nbr[0], net->geo.nbr[0], 1, n0, n0, false);
     // join: the caller's stream continues only after every weight gradient has landed
     if (net->side_used && net->live()) {

@@ -44,9 +44,19 @@ SIGNATURES = {
                                   c_void_p]),
     'urn_bn_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_gconv_part_bytes': (c_i64, [c_i64, c_int]),
+    'urn_gconv_fwd_ex': (c_int, [c_void_p, ctypes.POINTER(c_int), c_void_p]),
+    'urn_gconv_bwd_dw_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int,
+                                    c_void_p, c_void_p]),
+    'urn_bn_stats_partial': (c_int, [c_void_p, c_i64, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p]),
+    'urn_bn_finalize_fwd': (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
+    'urn_bn_finalize_bwd': (c_int, [c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_bn_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
     'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'urn_rows_scatter_add': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
-    'urn_net_create': (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, ctypes.POINTER(c_void_p)]),
+    'urn_net_create': (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, c_int, ctypes.POINTER(c_void_p)]),
     'urn_net_destroy': (None, [c_void_p]),
     'urn_net_param_count': (c_i64, [c_void_p]),
     'urn_net_running_count': (c_i64, [c_void_p]),
@@ -57,6 +67,7 @@ SIGNATURES = {
                                 ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_i64, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     'urn_net_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_set_option': (c_int, [ctypes.c_char_p, c_i64]),
     'urn_prof_enable': (c_int, [c_int]),
     'urn_prof_read': (c_int, [c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_i64)]),
 }

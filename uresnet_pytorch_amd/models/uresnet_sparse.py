@@ -32,12 +32,14 @@ class UResNet(torch.nn.Module):
         # fast path: the whole sparseModel inside the C++ executor (same kernels, one autograd node);
         # m must be a multiple of 16 (MFMA tiles).  use_executor=False keeps the per-layer path.
         self.use_executor = (dimension == 3 and m % 16 == 0)
+        self.executor_flags = 0     # lib URN_NET_UNFUSED (1) / URN_NET_SINGLE_STREAM (2): debug and A/B switches
         self._executor = None
 
     def _trunk(self, coords, features):
         if self._executor is None:
             f = self._flags
             self._executor = TrunkExecutor(self.sparseModel, f.URESNET_FILTERS, f.URESNET_NUM_STRIDES, 2, f.NUM_CLASS)
+            self._executor.flags = self.executor_flags
         ex = self._executor
         inp = self.sparseModel[0]
         c = coords.to(torch.int32) if coords.dtype != torch.int32 else coords

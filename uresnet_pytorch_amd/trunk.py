@@ -39,6 +39,7 @@ class TrunkExecutor:
     def __init__(self, sparse_model, m, num_levels, reps, num_class):
         self.model = sparse_model
         self.cfg = (m, num_levels, reps, num_class)
+        self.flags = 0            # URN_NET_UNFUSED = 1, URN_NET_SINGLE_STREAM = 2 (debug / A-B switches)
         self.handle = None
         self.slots = []
         self.flat = None
@@ -49,7 +50,8 @@ class TrunkExecutor:
     def _new_handle(self):
         L = _l.load()
         h = ctypes.c_void_p()
-        _l.check(L.urn_net_create(*self.cfg, float(self.eps), float(self.momentum), ctypes.byref(h)), 'net_create')
+        _l.check(L.urn_net_create(*self.cfg, float(self.eps), float(self.momentum), int(self.flags), ctypes.byref(h)),
+                 'net_create')
         return h
 
     def acquire(self):
