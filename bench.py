@@ -143,16 +143,18 @@ def main():
     value = total_voxels * args.steps / dt
 
     result = None
+    # roofline leg: instrumented steps after the timed region (HIP events on the launch stream).  EVERY rank runs
+    # them (the step contains a collective); only rank 0 records.
+    PSTEPS = 3
     if rank == 0:
-        # roofline leg: instrumented steps after the timed region (HIP events on the launch stream)
+        urn_lib.check(L.urn_prof_enable(1))
+    for _ in range(PSTEPS):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
         from uresnet_pytorch_amd import sparse_ops as so
         geo = so.SparseGeometry(data[:, :4].to(torch.int32), SPATIAL, STRIDES)
         flops_step, launches_step = conv_launch_flops(model, geo)
-        PSTEPS = 3
-        urn_lib.check(L.urn_prof_enable(1))
-        for _ in range(PSTEPS):
-            step()
-        torch.cuda.synchronize()
         ms = ctypes.c_double(); n = ctypes.c_int64()
         urn_lib.check(L.urn_prof_read(0, ctypes.byref(ms), ctypes.byref(n)))
         urn_lib.check(L.urn_prof_enable(0))

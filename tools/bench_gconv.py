@@ -21,11 +21,11 @@ def run(level, cin, cout, reps=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 shapes = [(0, 16, 16), (1, 32, 32), (2, 48, 48), (3, 64, 64), (4, 80, 80), (3, 128, 64), (2, 96, 48)]
-variants = [('pipe1 mw8192', 1, 8192), ('pipe0 mw8192', 0, 8192), ('pipe1 mw2048', 1, 2048), ('pipe0 mw2048', 0, 2048), ('pipe0 mw512', 0, 512), ('pipe1 mw512', 1, 512)]
+variants = [('full', 0), ('noMFMA', 1), ('noA', 2), ('noB', 4), ('noAB', 6), ('noBar', 8), ('noOffsets', 16), ('noMFMA,A,B', 7)]
 for lv, ci, co in shapes:
     out = []
-    for name, pipe, mw in variants:
-        L.urn_set_option(b'gconv_pipe', pipe); L.urn_set_option(b'gconv_min_waves', mw)
+    for name, mw in variants:
+        L.urn_set_option(b'gconv_kernel', 4); L.urn_set_option(b'gconv_dbg', mw)
         t = min(run(lv, ci, co) for _ in range(3))
         out.append('%s %.1f' % (name, t))
     fl = 2.0 * geo.rules[lv] * ci * co

@@ -24,6 +24,7 @@
 #include "urn_common.h"
 #include "urn_prof.h"
 #include "urn_gconv_int.h"
+#include <stdlib.h>
 #include <string.h>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -251,6 +252,8 @@ struct Pick { int mb, nb; };
 
 // tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
 // before the column tile is widened
+extern long g_lds_min_wgs;
+static int g_opt_dbg = 0;
 static int g_opt_pipe = 0;
 static int g_opt_kernel = 4;   // 4 = LDS-staged tile kernel (urn_gconv_lds.hip), 3 = register-gather kernel below
 static long g_opt_min_waves = 8192;
@@ -261,6 +264,8 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "gconv_pipe")) { g_opt_pipe = value != 0; return URN_OK; }
     if (!strcmp(key, "gconv_min_waves")) { g_opt_min_waves = value; return URN_OK; }
     if (!strcmp(key, "gconv_kernel")) { g_opt_kernel = (int)value; return URN_OK; }
+    if (!strcmp(key, "gconv_lds_min_wgs")) { g_lds_min_wgs = value; return URN_OK; }
+    if (!strcmp(key, "gconv_dbg")) { g_opt_dbg = (int)value; return URN_OK; }
     urn_set_error("urn_set_option: unknown key %s", key);
     return URN_EINVAL;
 }
@@ -328,14 +333,20 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
         URN_LAUNCH_CHECK();
         return URN_OK;
     }
+    static const bool env_once = [] {
+        if (const char *e = getenv("URN_GCONV_KERNEL")) g_opt_kernel = atoi(e);   // A/B switch: 3 register, 4 LDS, 5 LDS-DMA
+        return true;
+    }();
+    (void)env_once;
     const bool split = u->K >= 8;
     const Pick p = pick_tile(ks, u->cout / 16, u->n_out, split);
     GArgs a{u->x, u->wt, u->tbl, (long)u->ld, u->K, u->flip, nullptr, (long)u->n_out, u->cout, u->res, u->y,
-            u->xf_scale, u->xf_shift, u->epilogue, u->part, u->e_x, u->e_scale, u->e_shift, u->e_mean, u->e_invstd};
+            u->xf_scale, u->xf_shift, u->epilogue, u->part, u->e_x, u->e_scale, u->e_shift, u->e_mean, u->e_invstd, g_opt_dbg};
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_GCONV, st);
     bool ok = false;
-    if (g_opt_kernel == 4 && urn_gconv_lds_launch(a, ks, u->n_out, st)) {
+    if ((g_opt_kernel == 5 && urn_gconv_dma_launch(a, ks, u->n_out, st)) ||
+        (g_opt_kernel >= 4 && urn_gconv_lds_launch(a, ks, u->n_out, st))) {
         if (prof) urn_prof_end(st);
         if (n_tiles) *n_tiles = (int)((u->n_out + 15) / 16);
         URN_LAUNCH_CHECK();

@@ -16,7 +16,10 @@ struct GArgs {
     int epi;
     double *part;
     const float *e_x, *e_scale, *e_shift, *e_mean, *e_invstd;
+    int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };
 
 // LDS-staged variant (urn_gconv_lds.hip): returns false when it has no instantiation for the shape
 bool urn_gconv_lds_launch(const GArgs &a, int ks, long n_out, hipStream_t st);
+// LDS-DMA ring variant (urn_gconv_dma.hip)
+bool urn_gconv_dma_launch(const GArgs &a, int ks, long n_out, hipStream_t st);

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
         for (int e = tid; e < CIN; e += 256) { s_xf[0][e] = g.xf_scale[e]; s_xf[1][e] = g.xf_shift[e]; }
     __syncthreads();
     unsigned m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    if (g.dbg & 16) m = 0u;
 
     f32x4 acc[NB];
 #pragma unroll
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
     auto fetch = [&](f32x4 (&ra)[A_F4], f32x4 (&rb)[B_F4], int t) {
         if (t < 0) return;
         const int o = g.flip ? (K - 1 - t) : t;
+        if (!(g.dbg & 2))
         // unconditional loads (a missing neighbour reads row 0 and is zeroed when parked): a branch around a
         // load makes hipcc wait for each load separately and serialises the gather
 #pragma unroll
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
             ra[j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * CIN + 4 * c4);
         }
         const float *wo = g.wt + ((long)o * cout + col_base) * CIN;   // NB*16 contiguous rows of CIN floats
+        if (!(g.dbg & 4))
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             const int e = j * 256 + tid;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
             }
         }
         fetch(ra_f, rb_f, tf);
-        if (act) {
+        if (act && !(g.dbg & 1)) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -144,7 +147,11 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
                     for (int tt = 0; tt < 4; ++tt) acc[nb] = MFMA16(fa[ks][tt], fb[ks][nb][tt], acc[nb]);
         }
         park(ra_n, rb_n, tn, buf ^ 1);   // s_a[wave] is private and its fragments are already in registers
-        __syncthreads();
+        // The barrier only orders LDS traffic.  __syncthreads() would also wait for vmcnt(0) -- on gfx950 loads and
+        // stores share that counter -- and drain the two offsets of global prefetch every step.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(g.dbg & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
 
     // 2. offset loop, unrolled by three so that every register set has a static name
@@ -218,6 +225,8 @@ static void launch_lds(const GArgs &a, long n_out, hipStream_t st)
     hipLaunchKernelGGL((k_gconv_lds<KS, NB>), dim3((unsigned)blocks, a.cout / (NB * 16)), dim3(256), 0, st, a);
 }
 
+long g_lds_min_wgs = 1024;   // tuning knob (urn_set_option "gconv_lds_min_wgs")
+
 // LDS per workgroup: idx 7 KB + A 4*16*LDA*4 + B 2*NB*16*LDA*4  (LDA = cin+4); keep it <= 64 KB
 template <int KS>
 static bool launch_lds_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
@@ -229,7 +238,7 @@ static bool launch_lds_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
         if (nblk % d) continue;
         const long lds = 7168 + 4L * 16 * (KS * 16 + 4) * 4 + 2L * d * 16 * (KS * 16 + 4) * 4;
         if (lds > 65536) continue;
-        if (blocks * (nblk / d) >= 1024) { nb = d; break; }
+        if (blocks * (nblk / d) >= g_lds_min_wgs) { nb = d; break; }
     }
     if (nb == 4) { if constexpr (KS <= 6) { launch_lds<KS, 4>(a, n_out, st); return true; } nb = 2; }
     if (nb == 3) { if constexpr (KS <= 8) { launch_lds<KS, 3>(a, n_out, st); return true; } nb = 1; }
