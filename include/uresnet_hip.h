@@ -145,6 +145,20 @@ typedef struct {
     int epilogue;                  /* 0 none | 1 column stats of y | 2 BatchNorm-backward reduce */
     double *part;                  /* epilogue != 0: slab of urn_gconv_part_bytes(n_out, cout) bytes */
     const float *e_x, *e_scale, *e_shift, *e_mean, *e_invstd; /* epilogue 2: the BatchNorm's input (n_out, cout) and folded affine */
+    /* Optional: finalize the epilogue partials before the call's work completes, without a separate
+     * urn_bn_finalize_* launch where the kernel supports it (the last workgroup to finish reduces the slab:
+     * agent-scope release / ticket / acquire on `sync_word`, a zeroed device uint32 that the kernel resets).
+     * fin_n = row count of the statistics.  Epilogue 1: up to two consuming BatchNorms each receive
+     * mean/invstd/scale/shift over all cout columns (+ running-stat update when the pointers are set).
+     * Epilogue 2: dgamma/dbeta are accumulated into, coef0/coef1 written. */
+    uint32_t *sync_word;
+    int64_t fin_n;
+    double fin_eps, fin_momentum;
+    struct {
+        const float *gamma, *beta;
+        float *mean, *invstd, *scale, *shift, *running_mean, *running_var;
+    } fin_bn[2];
+    float *fin_dgamma, *fin_dbeta, *fin_coef0, *fin_coef1;
 } urn_gconv_args;
 int64_t urn_gconv_part_bytes(int64_t n_out, int cout);
 int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);

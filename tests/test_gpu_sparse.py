@@ -294,16 +294,10 @@ def test_fused_conv_pieces_vs_oracle(dev):
     y = torch.empty((n, cout), device=dev)
     part = torch.zeros(L.urn_gconv_part_bytes(n, cout) // 8, dtype=torch.float64, device=dev)
 
-    class A(ctypes.Structure):
-        _fields_ = [('x', ctypes.c_void_p), ('wt', ctypes.c_void_p), ('tbl', ctypes.c_void_p), ('ld', ctypes.c_int64),
-                    ('K', ctypes.c_int), ('flip', ctypes.c_int), ('n_out', ctypes.c_int64), ('cin', ctypes.c_int),
-                    ('cout', ctypes.c_int), ('res', ctypes.c_void_p), ('y', ctypes.c_void_p),
-                    ('xf_scale', ctypes.c_void_p), ('xf_shift', ctypes.c_void_p), ('epilogue', ctypes.c_int),
-                    ('part', ctypes.c_void_p), ('e_x', ctypes.c_void_p), ('e_scale', ctypes.c_void_p),
-                    ('e_shift', ctypes.c_void_p), ('e_mean', ctypes.c_void_p), ('e_invstd', ctypes.c_void_p)]
+    A = L_.GConvArgs
     npart = ctypes.c_int()
-    a = A(xt.data_ptr(), wt.data_ptr(), geo.nbr[0].data_ptr(), geo.ld, 27, 0, n, cin, cout, None, y.data_ptr(),
-          sc.data_ptr(), sh.data_ptr(), 1, part.data_ptr(), None, None, None, None, None)
+    a = A(x=xt.data_ptr(), wt=wt.data_ptr(), tbl=geo.nbr[0].data_ptr(), ld=geo.ld, K=27, flip=0, n_out=n, cin=cin, cout=cout,
+          y=y.data_ptr(), xf_scale=sc.data_ptr(), xf_shift=sh.data_ptr(), epilogue=1, part=part.data_ptr())
     L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a), ctypes.byref(npart), L_.stream()))
     assert rel(y.cpu().numpy(), y_ref) < TOL
     pp = part[:npart.value * 2 * cout].view(npart.value, 2, cout).sum(0).cpu().numpy()
@@ -319,9 +313,10 @@ def test_fused_conv_pieces_vs_oracle(dev):
     gbuf = torch.empty((n, cin), device=dev)
     part2 = torch.zeros(L.urn_gconv_part_bytes(n, cin) // 8, dtype=torch.float64, device=dev)
     mt, it = t(mean), t(invstd)
-    a2 = A(t(dy).data_ptr(), Wt.data_ptr(), geo.nbr[0].data_ptr(), geo.ld, 27, 1, n, cout, cin, None, gbuf.data_ptr(),
-           None, None, 2, part2.data_ptr(), xt.data_ptr(), sc.data_ptr(), sh.data_ptr(), mt.data_ptr(), it.data_ptr())
-    dyt = t(dy); a2.x = dyt.data_ptr()
+    dyt = t(dy)
+    a2 = A(x=dyt.data_ptr(), wt=Wt.data_ptr(), tbl=geo.nbr[0].data_ptr(), ld=geo.ld, K=27, flip=1, n_out=n, cin=cout, cout=cin,
+           y=gbuf.data_ptr(), epilogue=2, part=part2.data_ptr(), e_x=xt.data_ptr(), e_scale=sc.data_ptr(),
+           e_shift=sh.data_ptr(), e_mean=mt.data_ptr(), e_invstd=it.data_ptr())
     L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a2), ctypes.byref(npart), L_.stream()))
     dg = torch.zeros(cin, device=dev); db = torch.zeros(cin, device=dev); coef = torch.empty(2 * cin, device=dev)
     L_.check(L.urn_bn_finalize_bwd(part2.data_ptr(), npart.value, n, cin, dg.data_ptr(), db.data_ptr(), coef.data_ptr(),

@@ -254,6 +254,7 @@ struct Pick { int mb, nb; };
 // before the column tile is widened
 extern long g_lds_min_wgs;
 static int g_opt_dbg = 0;
+static int g_opt_fin_in_kernel = 0;
 static int g_opt_pipe = 0;
 static int g_opt_kernel = 4;   // 4 = LDS-staged tile kernel (urn_gconv_lds.hip), 3 = register-gather kernel below
 static long g_opt_min_waves = 8192;
@@ -266,6 +267,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "gconv_kernel")) { g_opt_kernel = (int)value; return URN_OK; }
     if (!strcmp(key, "gconv_lds_min_wgs")) { g_lds_min_wgs = value; return URN_OK; }
     if (!strcmp(key, "gconv_dbg")) { g_opt_dbg = (int)value; return URN_OK; }
+    if (!strcmp(key, "fin_in_kernel")) { g_opt_fin_in_kernel = value != 0; return URN_OK; }
     urn_set_error("urn_set_option: unknown key %s", key);
     return URN_EINVAL;
 }
@@ -312,6 +314,22 @@ static bool launch_ks(const GArgs &a, long n_out, Pick p, bool split, hipStream_
     return false;
 }
 
+// the finalize of the epilogue partials as separate launches
+static int finalize_launches(const urn_gconv_args *u, int np, void *stream)
+{
+    if (u->epilogue == 1) {
+        for (int i = 0; i < 2; ++i) {
+            if (!u->fin_bn[i].mean) continue;
+            int rc = urn_bn_finalize_fwd(u->part, np, u->fin_n, u->cout, u->cout, u->fin_eps, u->fin_bn[i].gamma, u->fin_bn[i].beta,
+                                         u->fin_bn[i].mean, u->fin_bn[i].invstd, u->fin_bn[i].scale, u->fin_bn[i].shift,
+                                         u->fin_bn[i].running_mean, u->fin_bn[i].running_var, u->fin_momentum, stream);
+            if (rc) return rc;
+        }
+        return URN_OK;
+    }
+    return urn_bn_finalize_bwd(u->part, np, u->fin_n, u->cout, u->fin_dgamma, u->fin_dbeta, u->fin_coef0, u->fin_coef1, stream);
+}
+
 extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *stream)
 {
     URN_CHECK_ARG(u, "null args");
@@ -340,18 +358,39 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     (void)env_once;
     const bool split = u->K >= 8;
     const Pick p = pick_tile(ks, u->cout / 16, u->n_out, split);
-    GArgs a{u->x, u->wt, u->tbl, (long)u->ld, u->K, u->flip, nullptr, (long)u->n_out, u->cout, u->res, u->y,
-            u->xf_scale, u->xf_shift, u->epilogue, u->part, u->e_x, u->e_scale, u->e_shift, u->e_mean, u->e_invstd, g_opt_dbg};
+    GArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = u->x; a.wt = u->wt; a.tbl = u->tbl; a.ld = (long)u->ld; a.K = u->K; a.flip = u->flip; a.n_cap = (long)u->n_out;
+    a.cout = u->cout; a.res = u->res; a.y = u->y; a.xf_scale = u->xf_scale; a.xf_shift = u->xf_shift; a.epi = u->epilogue;
+    a.part = u->part; a.e_x = u->e_x; a.e_scale = u->e_scale; a.e_shift = u->e_shift; a.e_mean = u->e_mean;
+    a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg;
+    // finalize requested?  In-kernel (last workgroup) only on request: measured on MI355X the tail work (every
+    // workgroup drains its stores and takes a ticket, the last one reduces the slab while the chip idles) costs
+    // more than the separate finalize launch it saves (6.58 vs 6.14 ms per cfg3 step), so the default is launches.
+    const bool want_fin = u->epilogue != 0 && (u->fin_bn[0].mean != nullptr || u->fin_dgamma != nullptr);
+    const bool in_kernel = want_fin && u->sync_word != nullptr && g_opt_fin_in_kernel;
+    if (want_fin) {
+        a.sync_word = in_kernel ? u->sync_word : nullptr; a.fin_n = (long)u->fin_n; a.fin_eps = u->fin_eps; a.fin_momentum = u->fin_momentum;
+        for (int i = 0; i < 2; ++i) {
+            a.fin_bn[i].gamma = u->fin_bn[i].gamma; a.fin_bn[i].beta = u->fin_bn[i].beta; a.fin_bn[i].mean = u->fin_bn[i].mean;
+            a.fin_bn[i].invstd = u->fin_bn[i].invstd; a.fin_bn[i].scale = u->fin_bn[i].scale; a.fin_bn[i].shift = u->fin_bn[i].shift;
+            a.fin_bn[i].running_mean = u->fin_bn[i].running_mean; a.fin_bn[i].running_var = u->fin_bn[i].running_var;
+        }
+        a.fin_dgamma = u->fin_dgamma; a.fin_dbeta = u->fin_dbeta; a.fin_coef0 = u->fin_coef0; a.fin_coef1 = u->fin_coef1;
+    }
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_GCONV, st);
     bool ok = false;
     if ((g_opt_kernel == 5 && urn_gconv_dma_launch(a, ks, u->n_out, st)) ||
         (g_opt_kernel >= 4 && urn_gconv_lds_launch(a, ks, u->n_out, st))) {
         if (prof) urn_prof_end(st);
-        if (n_tiles) *n_tiles = (int)((u->n_out + 15) / 16);
+        const int np = (int)((u->n_out + 63) / 64);   // one partial row per 64-row workgroup
+        if (n_tiles) *n_tiles = np;
         URN_LAUNCH_CHECK();
+        if (want_fin && !in_kernel) return finalize_launches(u, np, stream);
         return URN_OK;
     }
+    a.sync_word = nullptr;   // the register-gather kernel below has no in-kernel finalize
     switch (ks) {
     case 1: ok = launch_ks<1>(a, u->n_out, p, split, st); break;
     case 2: ok = launch_ks<2>(a, u->n_out, p, split, st); break;
@@ -366,8 +405,10 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     }
     if (prof) urn_prof_end(st);
     if (!ok) { urn_set_error("urn_gconv_fwd_ex: no kernel for cin=%d tile %dx%d", u->cin, p.mb, p.nb); return URN_EUNSUPPORTED; }
-    if (n_tiles) *n_tiles = (int)((u->n_out + p.mb * 16 - 1) / (p.mb * 16));
+    const int np = (int)((u->n_out + p.mb * 16 - 1) / (p.mb * 16));
+    if (n_tiles) *n_tiles = np;
     URN_LAUNCH_CHECK();
+    if (want_fin) return finalize_launches(u, np, stream);
     return URN_OK;
 }
 

@@ -16,6 +16,15 @@ struct GArgs {
     int epi;
     double *part;
     const float *e_x, *e_scale, *e_shift, *e_mean, *e_invstd;
+    // in-kernel finalize of the epilogue partials (see urn_gconv_args in include/uresnet_hip.h)
+    unsigned *sync_word;
+    long fin_n;
+    double fin_eps, fin_momentum;
+    struct FinBN {
+        const float *gamma, *beta;
+        float *mean, *invstd, *scale, *shift, *running_mean, *running_var;
+    } fin_bn[2];
+    float *fin_dgamma, *fin_dbeta, *fin_coef0, *fin_coef1;
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };
 

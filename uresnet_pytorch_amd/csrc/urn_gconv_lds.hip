@@ -173,8 +173,6 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
     }
 
     // 3. epilogue (per 16-row block).  C layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
-    if (row_base >= n_out) return;
-    const long tile = (long)blockIdx.x * 4 + wave;
     double s0[NB], s1[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) { s0[nb] = 0.0; s1[nb] = 0.0; }
@@ -203,18 +201,94 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
             g.y[off] = v;
         }
     }
-    if (g.epi != 0) {
+    if (g.epi == 0) return;   // kernel-uniform
+
+    // 4. column partials: wave -> workgroup (LDS, wave order) -> slab row blockIdx.x
+    __shared__ double s_p[2][4][NB * 16];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            double a0 = s0[nb], a1 = s1[nb];
-            a0 += __shfl_xor(a0, 16); a1 += __shfl_xor(a1, 16);
-            a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
-            if (q == 0) {
-                const int col = col_base + nb * 16 + r;
-                g.part[(tile * 2 + 0) * cout + col] = a0;
-                g.part[(tile * 2 + 1) * cout + col] = a1;
+    for (int nb = 0; nb < NB; ++nb) {
+        double a0 = s0[nb], a1 = s1[nb];
+        a0 += __shfl_xor(a0, 16); a1 += __shfl_xor(a1, 16);
+        a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
+        if (q == 0) { s_p[0][wave][nb * 16 + r] = a0; s_p[1][wave][nb * 16 + r] = a1; }
+    }
+    __syncthreads();
+    if (tid < NB * 16) {
+        const double v0 = ((s_p[0][0][tid] + s_p[0][1][tid]) + s_p[0][2][tid]) + s_p[0][3][tid];
+        const double v1 = ((s_p[1][0][tid] + s_p[1][1][tid]) + s_p[1][2][tid]) + s_p[1][3][tid];
+        // write-through (sc1) 8-byte stores: visible to the reducing workgroup without an agent-scope release
+        // fence, i.e. without a write-back of this XCD's whole L2 at the end of every workgroup
+        __hip_atomic_store(&g.part[((long)blockIdx.x * 2 + 0) * cout + col_base + tid], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g.part[((long)blockIdx.x * 2 + 1) * cout + col_base + tid], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!g.sync_word) return;   // kernel-uniform: the caller finalizes with a separate launch
+
+    // 5. the last workgroup to arrive reduces the slab (sc1 slab stores -> every wave's vmcnt(0) -> barrier ->
+    //    relaxed agent ticket; reducer: agent acquire -> plain loads; cdna_hip_programming.md, in-launch
+    //    split-K reduction recipe) and finalizes the BatchNorm quantities
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(g.sync_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == gridDim.x * gridDim.y - 1u);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    {
+        __shared__ double s_r[2][256];
+        const int n_part = gridDim.x;
+        const int cl = tid & 15, gi = tid >> 4;
+        for (int cb = 0; cb < cout; cb += 16) {
+            const int col = cb + cl;
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+            int p = gi;
+            for (; p + 16 < n_part; p += 32) {
+                a0 += g.part[((long)p * 2) * cout + col];
+                a1 += g.part[((long)p * 2 + 1) * cout + col];
+                b0 += g.part[((long)(p + 16) * 2) * cout + col];
+                b1 += g.part[((long)(p + 16) * 2 + 1) * cout + col];
             }
+            if (p < n_part) { a0 += g.part[((long)p * 2) * cout + col]; a1 += g.part[((long)p * 2 + 1) * cout + col]; }
+            s_r[0][tid] = a0 + b0; s_r[1][tid] = a1 + b1;
+            __syncthreads();
+            if (tid < 16) {
+                double v0 = 0.0, v1 = 0.0;
+                for (int j = 0; j < 16; ++j) { v0 += s_r[0][j * 16 + tid]; v1 += s_r[1][j * 16 + tid]; }
+                const long n = g.fin_n;
+                if (g.epi == 1) {
+                    const double mu = n > 0 ? v0 / (double)n : 0.0;
+                    double var = n > 0 ? v1 / (double)n - mu * mu : 0.0;
+                    if (var < 0.0) var = 0.0;
+                    const double is = 1.0 / sqrt(var + g.fin_eps);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const GArgs::FinBN &b = g.fin_bn[f];
+                        if (!b.mean) continue;
+                        b.mean[col] = (float)mu;
+                        b.invstd[col] = (float)is;
+                        const float sc = b.gamma[col] * (float)is;
+                        b.scale[col] = sc;
+                        b.shift[col] = fmaf(-(float)mu, sc, b.beta[col]);
+                        if (b.running_mean) b.running_mean[col] = (float)(g.fin_momentum * b.running_mean[col] + (1.0 - g.fin_momentum) * mu);
+                        if (b.running_var) b.running_var[col] = (float)(g.fin_momentum * b.running_var[col] + (1.0 - g.fin_momentum) * var);
+                    }
+                } else {
+                    const double invn = n > 0 ? 1.0 / (double)n : 0.0;
+                    g.fin_dbeta[col] += (float)v0;
+                    g.fin_dgamma[col] += (float)v1;
+                    g.fin_coef0[col] = (float)(v0 * invn);
+                    g.fin_coef1[col] = (float)(v1 * invn);
+                }
+            }
+            __syncthreads();
         }
+        if (tid == 0) *g.sync_word = 0u;   // ready for the next launch on this stream
     }
 }
 

@@ -52,12 +52,14 @@ struct BNP {
     const float *x = nullptr, *y = nullptr;
     float *mean = nullptr, *invstd = nullptr;
     float *scale = nullptr, *shift = nullptr;   // fused path: relu(x*scale + shift) == BatchNormReLU(x)
+    unsigned long stamp = 0;                   // forward in which the arrays above were carved
 };
 // column partials (sum, sum of squares; fp64) of a tensor, written by its producer's epilogue
 struct Stats { double *part = nullptr; int n_part = 0, ld = 0; };
 // an activation tensor of the fused path: rows, channels and where its statistics come from;
 // a channel concat carries two slabs (columns [0,c0) from st, [c0,c) from st2)
 struct Act { float *x = nullptr; int64_t n = 0; int c = 0; Stats st, st2; int c0 = 0; };
+struct Cons { BNP *bn = nullptr; int coff = 0; };
 struct Block { bool has_nin; ConvP nin; BNP bn1; ConvP conv1; BNP bn2; ConvP conv2; };
 struct ULevel {
     std::vector<Block> pre, post;
@@ -268,44 +270,67 @@ struct urn_net {
     //           finalize (dgamma, dbeta, coefficients) -> apply (+ residual-branch gradient).
     int fused = 1;
 
-    Act conv_f(ConvP &c, const Act &in, const BNP *xf, const int32_t *tbl, int64_t n_out, const float *res, bool stats)
+    // a BatchNorm that consumes a conv output: the producing kernel finalizes its statistics (columns
+    // [coff, coff + cout) of the BatchNorm when the consumer is the second half of a channel concat)
+    unsigned long fwd_stamp = 0;
+    uint32_t *sync_word = nullptr;
+
+    void alloc_bn(BNP &b)
+    {
+        if (b.stamp == fwd_stamp) return;
+        b.stamp = fwd_stamp;
+        b.mean = arena.f32(b.c); b.invstd = arena.f32(b.c); b.scale = arena.f32(b.c); b.shift = arena.f32(b.c);
+    }
+    Act conv_f(ConvP &c, const Act &in, const BNP *xf, const int32_t *tbl, int64_t n_out, const float *res, Cons c0,
+               Cons c1 = Cons())
     {
         c.x = in.x;
         Act y;
         y.n = n_out; y.c = c.cout;
         y.x = arena.f32(n_out * c.cout);
         const bool mfma = (c.cin % 16 == 0) && (c.cout % 16 == 0);
+        const bool stats = c0.bn != nullptr;
+        double *part = nullptr;
         if (stats) {
-            y.st.ld = c.cout;
-            y.st.part = (double *)arena.alloc_bytes(mfma ? (size_t)urn_gconv_part_bytes(n_out, c.cout)
-                                                          : (size_t)urn_bn_scratch_bytes(c.cout));
+            part = (double *)arena.alloc_bytes(mfma ? (size_t)urn_gconv_part_bytes(n_out, c.cout)
+                                                    : (size_t)urn_bn_scratch_bytes(c.cout));
+            alloc_bn(*c0.bn);
+            if (c1.bn) alloc_bn(*c1.bn);
         }
-        if (live()) {
-            urn_gconv_args a;
-            memset(&a, 0, sizeof(a));
-            a.x = in.x; a.wt = wt_all + c.w; a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
-            a.cin = c.cin; a.cout = c.cout; a.res = res; a.y = y.x;
-            if (xf) { a.xf_scale = xf->scale; a.xf_shift = xf->shift; }
-            if (stats && mfma) { a.epilogue = 1; a.part = y.st.part; }
-            check(urn_gconv_fwd_ex(&a, &y.st.n_part, st));
-            if (stats && !mfma) check(urn_bn_stats_partial(y.x, n_out, c.cout, y.st.part, &y.st.n_part, st));
+        if (!live()) return y;
+        urn_gconv_args a;
+        memset(&a, 0, sizeof(a));
+        a.x = in.x; a.wt = wt_all + c.w; a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
+        a.cin = c.cin; a.cout = c.cout; a.res = res; a.y = y.x;
+        if (xf) { a.xf_scale = xf->scale; a.xf_shift = xf->shift; }
+        const Cons cons[2] = {c0, c1};
+        if (stats && mfma) {
+            a.epilogue = 1; a.part = part; a.sync_word = sync_word; a.fin_n = n_out; a.fin_eps = eps; a.fin_momentum = momentum;
+            for (int i = 0; i < 2; ++i) {
+                if (!cons[i].bn) continue;
+                BNP &b = *cons[i].bn;
+                const int o = cons[i].coff;
+                a.fin_bn[i].gamma = params + b.w + o; a.fin_bn[i].beta = params + b.b + o;
+                a.fin_bn[i].mean = b.mean + o; a.fin_bn[i].invstd = b.invstd + o;
+                a.fin_bn[i].scale = b.scale + o; a.fin_bn[i].shift = b.shift + o;
+                a.fin_bn[i].running_mean = running ? running + b.run + o : nullptr;
+                a.fin_bn[i].running_var = running ? running + b.run + b.c + o : nullptr;
+            }
+        }
+        int n_part = 0;
+        check(urn_gconv_fwd_ex(&a, &n_part, st));
+        if (stats && !mfma) {   // the VALU fallback (1-channel stem) has no epilogue: separate passes
+            check(urn_bn_stats_partial(y.x, n_out, c.cout, part, &n_part, st));
+            for (int i = 0; i < 2; ++i) {
+                if (!cons[i].bn) continue;
+                BNP &b = *cons[i].bn;
+                const int o = cons[i].coff;
+                check(urn_bn_finalize_fwd(part, n_part, n_out, c.cout, c.cout, eps, params + b.w + o, params + b.b + o, b.mean + o,
+                                          b.invstd + o, b.scale + o, b.shift + o, running ? running + b.run + o : nullptr,
+                                          running ? running + b.run + b.c + o : nullptr, momentum, st));
+            }
         }
         return y;
-    }
-    void bn_finalize(BNP &b, const Act &in)
-    {
-        b.x = in.x;
-        b.mean = arena.f32(b.c); b.invstd = arena.f32(b.c); b.scale = arena.f32(b.c); b.shift = arena.f32(b.c);
-        if (!live()) return;
-        float *rm = running ? running + b.run : nullptr;
-        float *rv = running ? running + b.run + b.c : nullptr;
-        const int c0 = in.st2.part ? in.c0 : b.c;
-        check(urn_bn_finalize_fwd(in.st.part, in.st.n_part, in.n, c0, in.st.ld, eps, params + b.w, params + b.b, b.mean,
-                                  b.invstd, b.scale, b.shift, rm, rv, momentum, st));
-        if (in.st2.part)
-            check(urn_bn_finalize_fwd(in.st2.part, in.st2.n_part, in.n, b.c - c0, in.st2.ld, eps, params + b.w + c0,
-                                      params + b.b + c0, b.mean + c0, b.invstd + c0, b.scale + c0, b.shift + c0,
-                                      rm ? rm + c0 : nullptr, rv ? rv + c0 : nullptr, momentum, st));
     }
     void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out)
     {
@@ -336,44 +361,65 @@ struct urn_net {
             a.cin = c.cout; a.cout = c.cin; a.y = g;
             a.epilogue = 2; a.part = part;
             a.e_x = b.x; a.e_scale = b.scale; a.e_shift = b.shift; a.e_mean = b.mean; a.e_invstd = b.invstd;
+            a.sync_word = sync_word; a.fin_n = n_in;
+            a.fin_dgamma = grads + b.w; a.fin_dbeta = grads + b.b; a.fin_coef0 = coef; a.fin_coef1 = coef + c.cin;
             int n_part = 0;
             check(urn_gconv_fwd_ex(&a, &n_part, st));
-            check(urn_bn_finalize_bwd(part, n_part, n_in, c.cin, grads + b.w, grads + b.b, coef, coef + c.cin, st));
             check(urn_bn_bwd_apply(b.x, g, extra, n_in, c.cin, params + b.w, b.mean, b.invstd, coef, coef + c.cin, dx, st));
         }
         return dx;
     }
-    Act block_f(Block &k, const Act &x, int l)
+    // out0/out1: the BatchNorms that consume this block's output
+    Act block_f(Block &k, const Act &x, int l, Cons out0, Cons out1 = Cons())
     {
         const int64_t n = geo.n[l];
         const int32_t *nbr = geo.nbr[l];
         const float *sc = x.x;
-        if (k.has_nin) sc = conv_f(k.nin, x, nullptr, nbr + 13 * geo.ld, n, nullptr, false).x;
-        bn_finalize(k.bn1, x);
-        Act t = conv_f(k.conv1, x, &k.bn1, nbr, n, nullptr, true);
-        bn_finalize(k.bn2, t);
-        return conv_f(k.conv2, t, &k.bn2, nbr, n, sc, true);
+        if (k.has_nin) sc = conv_f(k.nin, x, nullptr, nbr + 13 * geo.ld, n, nullptr, Cons()).x;
+        Cons c_bn2; c_bn2.bn = &k.bn2;
+        Act t = conv_f(k.conv1, x, &k.bn1, nbr, n, nullptr, c_bn2);
+        k.bn2.x = t.x;
+        return conv_f(k.conv2, t, &k.bn2, nbr, n, sc, out0, out1);
     }
-    Act u_f(ULevel &lv, Act x, int l)
+    // out: the BatchNorm that consumes this U's output
+    Act u_f(ULevel &lv, Act x, int l, Cons out)
     {
-        for (auto &k : lv.pre) x = block_f(k, x, l);
+        const int P = planes[l];
+        for (size_t i = 0; i < lv.pre.size(); ++i) {
+            Cons c0, c1;
+            if (i + 1 < lv.pre.size()) c0.bn = &lv.pre[i + 1].bn1;
+            else if (lv.has_sub) { c0.bn = &lv.bn_d; c1.bn = &lv.post[0].bn1; }
+            else c0 = out;
+            x = block_f(lv.pre[i], x, l, c0, c1);
+            if (i + 1 < lv.pre.size()) lv.pre[i + 1].bn1.x = x.x;
+            else if (lv.has_sub) lv.bn_d.x = x.x;
+        }
         if (lv.has_sub) {
             const int64_t n = geo.n[l], nc_ = geo.n[l + 1];
-            const int P = planes[l];
-            bn_finalize(lv.bn_d, x);
-            Act t = conv_f(lv.down, x, &lv.bn_d, geo.chd[l], nc_, nullptr, true);
-            t = u_f(*lv.sub, t, l + 1);
-            bn_finalize(lv.bn_u, t);
-            Act z = conv_f(lv.up, t, &lv.bn_u, geo.up[l], n, nullptr, true);
+            Cons c_sub; c_sub.bn = &lv.sub->pre[0].bn1;
+            Act t = conv_f(lv.down, x, &lv.bn_d, geo.chd[l], nc_, nullptr, c_sub);
+            lv.sub->pre[0].bn1.x = t.x;
+            Cons c_up; c_up.bn = &lv.bn_u;
+            t = u_f(*lv.sub, t, l + 1, c_up);
+            lv.bn_u.x = t.x;
+            Cons c_cat; c_cat.bn = &lv.post[0].bn1; c_cat.coff = P;
+            Act z = conv_f(lv.up, t, &lv.bn_u, geo.up[l], n, nullptr, c_cat);
             Act cat;
-            cat.n = n; cat.c = 2 * P; cat.c0 = P; cat.st = x.st; cat.st2 = z.st;
+            cat.n = n; cat.c = 2 * P;
             cat.x = arena.f32(n * 2 * P);
             if (live()) {
                 check(hipMemcpy2DAsync(cat.x, 2 * P * 4, x.x, P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
                 check(hipMemcpy2DAsync(cat.x + P, 2 * P * 4, z.x, P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
             }
+            lv.post[0].bn1.x = cat.x;
             x = cat;
-            for (auto &k : lv.post) x = block_f(k, x, l);
+            for (size_t i = 0; i < lv.post.size(); ++i) {
+                Cons c0;
+                if (i + 1 < lv.post.size()) c0.bn = &lv.post[i + 1].bn1;
+                else c0 = out;
+                x = block_f(lv.post[i], x, l, c0);
+                if (i + 1 < lv.post.size()) lv.post[i + 1].bn1.x = x.x;
+            }
         }
         return x;
     }
@@ -534,13 +580,19 @@ static void run_forward(urn_net *net, const float *site_feats)
     transpose_all(net);
     const int64_t n0 = net->geo.n[0];
     if (net->fused) {
+        net->fwd_stamp++;
+        net->sync_word = (uint32_t *)net->arena.alloc_bytes(256);
+        if (net->live()) net->check(hipMemsetAsync(net->sync_word, 0, 256, net->st) == hipSuccess ? URN_OK : URN_EHIP);
         Act f;
         f.x = const_cast<float *>(site_feats); f.n = n0; f.c = 1;
-        Act x = net->conv_f(net->stem, f, nullptr, net->geo.nbr[0], n0, nullptr, true);
-        x = net->u_f(net->u, x, 0);
+        Cons c_first; c_first.bn = &net->u.pre[0].bn1;
+        Act x = net->conv_f(net->stem, f, nullptr, net->geo.nbr[0], n0, nullptr, c_first);
+        net->u.pre[0].bn1.x = x.x;
+        Cons c_out; c_out.bn = &net->bn_out;
+        x = net->u_f(net->u, x, 0, c_out);
         // the last BatchNormReLU feeds the OutputLayer, not a conv: materialise it
         BNP &b = net->bn_out;
-        net->bn_finalize(b, x);
+        b.x = x.x;
         float *y = net->arena.f32(n0 * b.c);
         b.y = y;
         if (net->live())

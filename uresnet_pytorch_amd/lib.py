@@ -14,6 +14,24 @@ _lib = None
 
 c_void_p, c_int, c_i64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 
+class _FinBN(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ('gamma', 'beta', 'mean', 'invstd', 'scale', 'shift', 'running_mean',
+                                                 'running_var')]
+
+
+class GConvArgs(ctypes.Structure):
+    """urn_gconv_args of include/uresnet_hip.h"""
+    _fields_ = [('x', ctypes.c_void_p), ('wt', ctypes.c_void_p), ('tbl', ctypes.c_void_p), ('ld', ctypes.c_int64),
+                ('K', ctypes.c_int), ('flip', ctypes.c_int), ('n_out', ctypes.c_int64), ('cin', ctypes.c_int),
+                ('cout', ctypes.c_int), ('res', ctypes.c_void_p), ('y', ctypes.c_void_p),
+                ('xf_scale', ctypes.c_void_p), ('xf_shift', ctypes.c_void_p), ('epilogue', ctypes.c_int),
+                ('part', ctypes.c_void_p), ('e_x', ctypes.c_void_p), ('e_scale', ctypes.c_void_p),
+                ('e_shift', ctypes.c_void_p), ('e_mean', ctypes.c_void_p), ('e_invstd', ctypes.c_void_p),
+                ('sync_word', ctypes.c_void_p), ('fin_n', ctypes.c_int64), ('fin_eps', ctypes.c_double),
+                ('fin_momentum', ctypes.c_double), ('fin_bn', _FinBN * 2), ('fin_dgamma', ctypes.c_void_p),
+                ('fin_dbeta', ctypes.c_void_p), ('fin_coef0', ctypes.c_void_p), ('fin_coef1', ctypes.c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/uresnet_hip.h
 SIGNATURES = {
     'urn_version': (c_int, []),
