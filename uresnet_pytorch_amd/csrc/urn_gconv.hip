@@ -146,21 +146,43 @@ __global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, c
     }
 }
 
-__global__ void k_gconv_dw_small(const float *__restrict__ x, const float *__restrict__ dy,
-                                 const int *__restrict__ tbl, long ld, long n_out, int cin, int cout,
-                                 long chunk, float *__restrict__ dw)
+// VALU weight gradient for channel counts that are not multiples of 16 (the 1-channel stem).
+// grid (chunks, K); 256 threads = (cin*cout) pairs x R row lanes; LDS reduction over the row lanes,
+// one atomic per (pair, block).
+__global__ __launch_bounds__(256) void k_gconv_dw_small(const float *__restrict__ x, const float *__restrict__ dy,
+                                                        const int *__restrict__ tbl, long ld, long n_out, int cin, int cout,
+                                                        long chunk, float *__restrict__ dw)
 {
-    // grid (chunks, K); thread e -> (ci, co) pairs, strided
-    const int o = blockIdx.y;
+    __shared__ float s_acc[256];
+    const int o = blockIdx.y, t = threadIdx.x;
+    const int pairs = cin * cout;
     const long row_begin = (long)blockIdx.x * chunk, row_end = min(n_out, row_begin + chunk);
-    for (int e = threadIdx.x; e < cin * cout; e += blockDim.x) {
-        int ci = e / cout, co = e - ci * cout;
+    if (pairs <= 256) {
+        const int R = 256 / pairs, pair = t % pairs, rl = t / pairs;
+        const int ci = pair / cout, co = pair - ci * cout;
         float acc = 0.f;
-        for (long j = row_begin; j < row_end; ++j) {
-            int i = tbl[(long)o * ld + j];
-            if (i >= 0) acc = fmaf(x[(long)i * cin + ci], dy[j * cout + co], acc);
+        if (rl < R)
+            for (long j = row_begin + rl; j < row_end; j += R) {
+                const int i = tbl[(long)o * ld + j];
+                if (i >= 0) acc = fmaf(x[(long)i * cin + ci], dy[j * cout + co], acc);
+            }
+        s_acc[t] = acc;
+        __syncthreads();
+        if (t < pairs) {
+            float v = 0.f;
+            for (int k = 0; k < R; ++k) v += s_acc[k * pairs + t];
+            atomicAdd(&dw[((long)o * cin + ci) * cout + co], v);
         }
-        atomicAdd(&dw[((long)o * cin + ci) * cout + co], acc);
+    } else {
+        for (int e = t; e < pairs; e += 256) {
+            const int ci = e / cout, co = e - ci * cout;
+            float acc = 0.f;
+            for (long j = row_begin; j < row_end; ++j) {
+                const int i = tbl[(long)o * ld + j];
+                if (i >= 0) acc = fmaf(x[(long)i * cin + ci], dy[j * cout + co], acc);
+            }
+            atomicAdd(&dw[((long)o * cin + ci) * cout + co], acc);
+        }
     }
 }
 
@@ -181,10 +203,10 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
     hipStream_t st = (hipStream_t)stream;
     if ((cin % 16) || (cout % 16)) {
         if (xf_scale) { urn_set_error("urn_gconv_bwd_dw_ex: input transform needs channel counts that are multiples of 16"); return URN_EUNSUPPORTED; }
-        int chunks = (int)((n_out + 1023) / 1024);
+        int chunks = (int)((n_out + 255) / 256);
         if (chunks > 128) chunks = 128;
         long chunk = (n_out + chunks - 1) / chunks;
-        hipLaunchKernelGGL(k_gconv_dw_small, dim3(chunks, K), dim3(64), 0, st, x, dy, tbl, (long)ld, (long)n_out,
+        hipLaunchKernelGGL(k_gconv_dw_small, dim3(chunks, K), dim3(256), 0, st, x, dy, tbl, (long)ld, (long)n_out,
                            cin, cout, chunk, dw);
         URN_LAUNCH_CHECK();
         return URN_OK;

@@ -483,7 +483,12 @@ extern "C" int urn_net_create(int m, int num_levels, int reps, int num_class, do
     n->bn_out = n->make_bn(m);
     // side stream + a ring of events for the fork/join of the weight-gradient kernels; if the runtime is not
     // available (no GPU: build check, workspace sizing) the executor stays single-stream
-    if (!(flags & URN_NET_SINGLE_STREAM) && hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking) == hipSuccess) {
+    // lowest priority: the weight gradients only have to be done by the end of backward; the dX -> BatchNorm chain
+    // on the caller's stream is the critical path and should win the CUs when both have work
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (!(flags & URN_NET_SINGLE_STREAM) &&
+        hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, prio_lo) == hipSuccess) {
         for (int i = 0; i < 128; ++i) {
             hipEvent_t e;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
