@@ -184,6 +184,25 @@ int urn_rows_gather(const float *x, const int32_t *idx, int64_t n, int c, float 
 int urn_rows_scatter_add(const float *dy, const int32_t *idx, int64_t n, int c, float *dx,
                          void *stream);
 
+/* ---- head and loss on the device -------------------------------------------------
+ * urn_head_fwd: logits[i,:] = x[row2site[i],:] @ W^T + b -- scn.OutputLayer + torch.nn.Linear (reference
+ * uresnet_sparse.py:24-25,36) in one pass; row2site NULL = identity.  W is (nc, m) like Linear.weight.
+ * urn_head_bwd: dx (+= with atomics when row2site is given, plain stores otherwise), dW and db ACCUMULATED.
+ * urn_ce_fwd / urn_ce_bwd: SegmentationLoss (reference uresnet_sparse.py:46-82): per-event mean of the
+ * (optionally weighted) voxel cross-entropy, summed over events; out[0] = loss, out[1] = sum of per-event
+ * accuracies.  batch ids and labels are the float columns the reference passes (data[:, -2], label[:, 0]);
+ * ev = scratch of urn_ce_scratch_bytes(), row_lse (n) is kept for the backward.  No host sync per event. */
+int urn_head_fwd(const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W,
+                 const float *b, float *logits, void *stream);
+int urn_head_bwd(const float *dlogits, const float *x, const int32_t *row2site, int64_t n, int m, int nc,
+                 const float *W, float *dx, float *dW, float *db, void *stream);
+int64_t urn_ce_scratch_bytes(void);
+int urn_ce_fwd(const float *logits, const float *label, const float *batch_id, int batch_id_stride,
+               const float *weight, int64_t n, int nc, float *row_lse, double *ev, float *out, void *stream);
+int urn_ce_bwd(const float *logits, const float *label, const float *batch_id, int batch_id_stride,
+               const float *weight, const float *row_lse, const double *ev, const float *grad_out, int64_t n,
+               int nc, float *dlogits, void *stream);
+
 /* ------------------------------------------------------------------ whole-network executor
  * The trunk of the sparse model -- everything between scn.InputLayer and torch.nn.Linear at
  * reference uresnet_sparse.py:19-25 -- run from C++: the same kernels as the per-layer entry

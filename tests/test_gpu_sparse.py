@@ -351,3 +351,40 @@ def test_executor_two_forwards_before_backward(dev):
         res.append({k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()})
     for k in res[0]:
         assert rel(res[0][k], res[1][k]) < 1e-5, k
+
+
+def test_head_and_loss_kernels_vs_torch(dev):
+    """urn_head_* (OutputLayer+Linear) and urn_ce_* (per-event mean CE, accuracy) against torch / the oracle."""
+    from uresnet_pytorch_amd import sparse_ops as so
+    rng = np.random.default_rng(11)
+    n, m, nc = 5000, 16, 5
+    rows = rng.normal(size=(n, m)).astype(np.float32)
+    W = (rng.normal(size=(nc, m)) * 0.3).astype(np.float32); b = rng.normal(size=nc).astype(np.float32)
+    data = np.zeros((n, 5), np.float32); data[:, 3] = rng.integers(0, 3, size=n) * 2     # batch ids 0, 2, 4 (gaps)
+    lab = rng.integers(0, nc, size=(n, 1)).astype(np.float32)
+    wgt = rng.uniform(0.5, 2.0, size=(n, 1)).astype(np.float32)
+    for use_w in (False, True):
+        rt = torch.from_numpy(rows).to(dev).requires_grad_(True)
+        Wt = torch.from_numpy(W).to(dev).requires_grad_(True); bt = torch.from_numpy(b).to(dev).requires_grad_(True)
+        logits = so.HeadFunction.apply(rt, Wt, bt)
+        wt_ = torch.from_numpy(wgt).to(dev) if use_w else None
+        loss, out = so.SegmentationCEFunction.apply(logits, torch.from_numpy(data).to(dev), torch.from_numpy(lab).to(dev), wt_)
+        (2.5 * loss).backward()
+        # references: float64 torch on the CPU + the oracle's loss
+        r64 = torch.tensor(rows, dtype=torch.float64, requires_grad=True)
+        W64 = torch.tensor(W, dtype=torch.float64, requires_grad=True); b64 = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+        l64 = r64 @ W64.t() + b64
+        assert rel(logits.detach().cpu().numpy(), l64.detach().numpy()) < TOL
+        loss_ref, acc_ref, _ = orc.segmentation_loss(l64.detach().numpy().astype(np.float32), data, lab, wgt if use_w else None)
+        assert abs(loss.item() - loss_ref) < 1e-5 * abs(loss_ref) and abs(out[1].item() - acc_ref) < 1e-5
+        tl = 0
+        bid = torch.tensor(data[:, 3]); labt = torch.tensor(lab[:, 0]).long()
+        for e in bid.unique():
+            mk = bid == e
+            ce = torch.nn.functional.cross_entropy(l64[mk], labt[mk], reduction='none')
+            if use_w:
+                ce = ce * torch.tensor(wgt[:, 0], dtype=torch.float64)[mk]
+            tl = tl + ce.mean()
+        (2.5 * tl).backward()
+        assert rel(rt.grad.cpu().numpy(), r64.grad.numpy()) < TOL
+        assert rel(Wt.grad.cpu().numpy(), W64.grad.numpy()) < TOL and rel(bt.grad.cpu().numpy(), b64.grad.numpy()) < TOL

@@ -1,0 +1,251 @@
+// Network head and loss on the device: scn.OutputLayer + torch.nn.Linear
+// (reference uresnet/models/uresnet_sparse.py:24-25,36) as one gather+GEMV kernel, and the per-event
+// mean cross-entropy / accuracy of SegmentationLoss (reference uresnet_sparse.py:46-82) without a
+// host synchronisation per event.  HBM-bound streaming kernels; N x 16 x 5 is far too small for MFMA.
+#include "urn_common.h"
+
+#define HEAD_MAXC 32     // classes
+#define HEAD_MAXM 256    // trunk width
+#define CE_MAXEV 1024    // batch ids handled by the loss
+
+// logits[i,:] = x[row2site[i],:] @ W^T + b          W is (nc, m) like torch.nn.Linear.weight
+__global__ __launch_bounds__(256) void k_head_fwd(const float *__restrict__ x, const int *__restrict__ row2site, long n,
+                                                  int m, int nc, const float *__restrict__ W, const float *__restrict__ b,
+                                                  float *__restrict__ logits)
+{
+    __shared__ float s_w[HEAD_MAXC * HEAD_MAXM / 8];   // nc*m <= 1024 floats
+    __shared__ float s_b[HEAD_MAXC];
+    for (int e = threadIdx.x; e < nc * m; e += 256) s_w[e] = W[e];
+    if (threadIdx.x < nc) s_b[threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *xi = x + (row2site ? (long)row2site[i] : i) * m;
+    float acc[HEAD_MAXC];
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c) acc[c] = 0.f;
+    for (int k = 0; k < m; k += 4) {
+        const f32x4 v = *(const f32x4 *)(xi + k);
+#pragma unroll
+        for (int c = 0; c < HEAD_MAXC; ++c)
+            if (c < nc) {
+                const float *w = s_w + c * m + k;
+                acc[c] = fmaf(v[0], w[0], fmaf(v[1], w[1], fmaf(v[2], w[2], fmaf(v[3], w[3], acc[c]))));
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c)
+        if (c < nc) logits[i * nc + c] = acc[c] + s_b[c];
+}
+
+// dx[row2site[i],:] += dl[i,:] @ W ; dW += dl^T @ x_rows ; db += sum dl        (all accumulated; caller zeroes)
+__global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ dl, const float *__restrict__ x,
+                                                  const int *__restrict__ row2site, long n, int m, int nc,
+                                                  const float *__restrict__ W, float *__restrict__ dx,
+                                                  float *__restrict__ dW, float *__restrict__ db)
+{
+    __shared__ float s_w[HEAD_MAXC * HEAD_MAXM / 8];
+    __shared__ float s_dl[256][HEAD_MAXC / 4 + 1];      // nc <= 8 fast path rows of 9 floats
+    __shared__ float s_x[256][17];                       // m == 16 fast path
+    for (int e = threadIdx.x; e < nc * m; e += 256) s_w[e] = W[e];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float d[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d[c] = 0.f;
+    long site = -1;
+    if (i < n) {
+        site = row2site ? (long)row2site[i] : i;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < nc) d[c] = dl[i * nc + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s_dl[threadIdx.x][c] = d[c];
+    __syncthreads();
+    if (i < n) {
+        const float *xi = x + site * m;
+        for (int k = 0; k < m; ++k) {
+            float g = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < nc) g = fmaf(d[c], s_w[c * m + k], g);
+            if (row2site) atomicAdd(&dx[site * m + k], g);   // several input rows may share a site
+            else dx[site * m + k] = g;                         // identity map: plain store
+            if (m == 16) s_x[threadIdx.x][k] = xi[k];
+        }
+    } else if (m == 16) {
+        for (int k = 0; k < 16; ++k) s_x[threadIdx.x][k] = 0.f;
+    }
+    __syncthreads();
+    // block-level dW / db: thread e = (c, k) sums over the block's 256 rows
+    for (int e = threadIdx.x; e < nc * m; e += 256) {
+        const int c = e / m, k = e - c * m;
+        float acc = 0.f;
+        if (m == 16) {
+            for (int r = 0; r < 256; ++r) acc = fmaf(s_dl[r][c], s_x[r][k], acc);
+        } else {
+            const long base = (long)blockIdx.x * 256;
+            for (int r = 0; r < 256 && base + r < n; ++r) acc = fmaf(s_dl[r][c], x[(row2site ? (long)row2site[base + r] : base + r) * m + k], acc);
+        }
+        atomicAdd(&dW[e], acc);
+    }
+    if (threadIdx.x < nc) {
+        float acc = 0.f;
+        for (int r = 0; r < 256; ++r) acc += s_dl[r][threadIdx.x];
+        atomicAdd(&db[threadIdx.x], acc);
+    }
+}
+
+extern "C" int urn_head_fwd(const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W,
+                            const float *b, float *logits, void *stream)
+{
+    if (n <= 0) return URN_OK;
+    URN_CHECK_ARG(x && W && logits, "null pointer");
+    URN_CHECK_ARG(m > 0 && m % 4 == 0 && nc > 0 && nc <= HEAD_MAXC && nc * m <= HEAD_MAXC * HEAD_MAXM / 8, "unsupported head shape");
+    hipLaunchKernelGGL(k_head_fwd, dim3(urn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, row2site, (long)n, m, nc, W, b,
+                       logits);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_head_bwd(const float *dlogits, const float *x, const int32_t *row2site, int64_t n, int m, int nc,
+                            const float *W, float *dx, float *dW, float *db, void *stream)
+{
+    if (n <= 0) return URN_OK;
+    URN_CHECK_ARG(dlogits && x && W && dx && dW && db, "null pointer");
+    URN_CHECK_ARG(m > 0 && nc > 0 && nc <= 8 && nc * m <= HEAD_MAXC * HEAD_MAXM / 8, "unsupported head shape (nc <= 8)");
+    hipLaunchKernelGGL(k_head_bwd, dim3(urn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dlogits, x, row2site, (long)n, m, nc,
+                       W, dx, dW, db);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// ---- per-event mean cross-entropy ------------------------------------------------------------
+// pass 1: per row log-softmax CE (optionally weighted) and argmax hit; per-event sums with atomics:
+//         ev[e] = (sum w*ce, row count, hits)   (double, float-exact counts)
+__global__ __launch_bounds__(256) void k_ce_fwd(const float *__restrict__ logits, const float *__restrict__ label,
+                                                const float *__restrict__ bid, int bid_stride,
+                                                const float *__restrict__ weight, long n, int nc,
+                                                float *__restrict__ row_lse, double *__restrict__ ev)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i < n;
+    double ce = 0.0, one = 0.0, hit = 0.0;
+    int e = -1;
+    if (ok) {
+        const float *l = logits + i * nc;
+        float mx = l[0];
+        int am = 0;
+        for (int c = 1; c < nc; ++c)
+            if (l[c] > mx) { mx = l[c]; am = c; }
+        float s = 0.f;
+        for (int c = 0; c < nc; ++c) s += expf(l[c] - mx);
+        const float lse = mx + logf(s);
+        row_lse[i] = lse;
+        const int lab = (int)label[i];
+        e = (int)bid[i * bid_stride];
+        const float w = weight ? weight[i] : 1.f;
+        ce = (double)((lse - l[lab]) * w);
+        one = 1.0;
+        hit = am == lab ? 1.0 : 0.0;
+    }
+    // rows of one event are contiguous in practice: when the whole wave belongs to one event, reduce in
+    // the wave and issue 3 atomics instead of 192 (all rows would otherwise hit the same three addresses)
+    const int e0 = __shfl(e, 0);
+    const bool uniform = __all(!ok || e == e0) && e0 >= 0;
+    __shared__ int s_e[4];
+    __shared__ double s_v[4][3];
+    const int wave = threadIdx.x >> 6;
+    if (uniform) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { ce += __shfl_xor(ce, d); one += __shfl_xor(one, d); hit += __shfl_xor(hit, d); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_e[wave] = uniform ? e0 : -1;
+        s_v[wave][0] = ce; s_v[wave][1] = one; s_v[wave][2] = hit;
+    }
+    __syncthreads();
+    const bool block_uniform = s_e[0] >= 0 && s_e[1] == s_e[0] && s_e[2] == s_e[0] && s_e[3] == s_e[0];
+    if (block_uniform) {   // one event in the whole block: 3 atomics per block
+        if (threadIdx.x < 3)
+            atomicAdd(&ev[3 * s_e[0] + threadIdx.x], ((s_v[0][threadIdx.x] + s_v[1][threadIdx.x]) + s_v[2][threadIdx.x]) + s_v[3][threadIdx.x]);
+    } else if (uniform) {
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ev[3 * e0 + 0], ce);
+            atomicAdd(&ev[3 * e0 + 1], one);
+            atomicAdd(&ev[3 * e0 + 2], hit);
+        }
+    } else if (ok) {
+        atomicAdd(&ev[3 * e + 0], ce);
+        atomicAdd(&ev[3 * e + 1], one);
+        atomicAdd(&ev[3 * e + 2], hit);
+    }
+}
+
+// pass 2: loss = sum_e mean_e, acc = sum_e hits_e/count_e  (out[0], out[1]); one small block
+__global__ void k_ce_reduce(const double *__restrict__ ev, int nev, float *__restrict__ out)
+{
+    __shared__ double s0[256], s1[256];
+    double a = 0.0, b = 0.0;
+    for (int e = threadIdx.x; e < nev; e += 256) {
+        const double cnt = ev[3 * e + 1];
+        if (cnt > 0.0) { a += ev[3 * e + 0] / cnt; b += ev[3 * e + 2] / cnt; }
+    }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) { s0[threadIdx.x] += s0[threadIdx.x + d]; s1[threadIdx.x] += s1[threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = (float)s0[0]; out[1] = (float)s1[0]; }
+}
+
+// backward: dlogits[i,c] = gout * w_i / count_e * (softmax_ic - [c == label_i])
+__global__ __launch_bounds__(256) void k_ce_bwd(const float *__restrict__ logits, const float *__restrict__ label,
+                                                const float *__restrict__ bid, int bid_stride,
+                                                const float *__restrict__ weight, const float *__restrict__ row_lse,
+                                                const double *__restrict__ ev, const float *__restrict__ gout, long n,
+                                                int nc, float *__restrict__ dlogits)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int lab = (int)label[i];
+    const int e = (int)bid[i * bid_stride];
+    const float w = weight ? weight[i] : 1.f;
+    const float scale = gout[0] * w / (float)ev[3 * e + 1];
+    const float lse = row_lse[i];
+    for (int c = 0; c < nc; ++c) {
+        const float p = expf(logits[i * nc + c] - lse);
+        dlogits[i * nc + c] = scale * (p - (c == lab ? 1.f : 0.f));
+    }
+}
+
+extern "C" int64_t urn_ce_scratch_bytes(void) { return (int64_t)CE_MAXEV * 3 * 8; }
+
+extern "C" int urn_ce_fwd(const float *logits, const float *label, const float *batch_id, int batch_id_stride,
+                          const float *weight, int64_t n, int nc, float *row_lse, double *ev, float *out, void *stream)
+{
+    URN_CHECK_ARG(ev && out && n >= 0 && nc > 0 && nc <= HEAD_MAXC, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ev, 0, (size_t)urn_ce_scratch_bytes(), st) != hipSuccess) { urn_set_error("urn_ce_fwd: memset failed"); return URN_EHIP; }
+    if (n > 0) {
+        URN_CHECK_ARG(logits && label && batch_id && row_lse && batch_id_stride > 0, "null pointer");
+        hipLaunchKernelGGL(k_ce_fwd, dim3(urn_cdiv(n, 256)), dim3(256), 0, st, logits, label, batch_id, batch_id_stride, weight,
+                           (long)n, nc, row_lse, ev);
+    }
+    hipLaunchKernelGGL(k_ce_reduce, dim3(1), dim3(256), 0, st, ev, CE_MAXEV, out);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_ce_bwd(const float *logits, const float *label, const float *batch_id, int batch_id_stride,
+                          const float *weight, const float *row_lse, const double *ev, const float *grad_out, int64_t n,
+                          int nc, float *dlogits, void *stream)
+{
+    if (n <= 0) return URN_OK;
+    URN_CHECK_ARG(logits && label && batch_id && row_lse && ev && grad_out && dlogits, "null pointer");
+    hipLaunchKernelGGL(k_ce_bwd, dim3(urn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, label, batch_id,
+                       batch_id_stride, weight, row_lse, ev, grad_out, (long)n, nc, dlogits);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}

@@ -74,6 +74,14 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'urn_rows_scatter_add': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    'urn_head_fwd': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_head_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p]),
+    'urn_ce_scratch_bytes': (c_i64, []),
+    'urn_ce_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p,
+                           c_void_p]),
+    'urn_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
+                           c_void_p, c_void_p]),
     'urn_net_create': (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, c_int, ctypes.POINTER(c_void_p)]),
     'urn_net_destroy': (None, [c_void_p]),
     'urn_net_param_count': (c_i64, [c_void_p]),

@@ -55,7 +55,10 @@ class UResNet(torch.nn.Module):
             x = self._trunk(coords, features)
         else:
             x = self.sparseModel((coords, features))
-        x = self.linear(x)
+        if x.is_cuda:   # Linear on the HIP head kernel (same parameters: self.linear.weight / .bias)
+            x = so.HeadFunction.apply(x, self.linear.weight, self.linear.bias)
+        else:
+            x = self.linear(x)
         return [x]
 
 
@@ -76,8 +79,16 @@ class SegmentationLoss(torch.nn.modules.loss._Loss):
         total_loss = 0
         total_acc = 0
         for i in range(len(segmentation)):
+            if segmentation[i].is_cuda:
+                # one fused pass on the device: per-event sums, no host sync per event
+                d = data[i] if (data[i].dtype == torch.float32 and data[i].is_contiguous()) else data[i].float().contiguous()
+                lab = label[i] if label[i].dtype == torch.float32 else label[i].float()
+                w = None if weight is None else weight[i]
+                loss_i, out = so.SegmentationCEFunction.apply(segmentation[i], d, lab, w)
+                total_loss = total_loss + loss_i
+                total_acc = total_acc + out[1]
+                continue
             batch_ids = data[i][:, -2]
-            # one pass over events without a host sync per event: per-event means via index_add
             ids, inv = torch.unique(batch_ids, return_inverse=True)
             nev = ids.numel()
             event_label = torch.squeeze(label[i], dim=-1).long()

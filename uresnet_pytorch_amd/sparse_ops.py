@@ -228,3 +228,74 @@ class RowsGatherFunction(torch.autograd.Function):
         _l.check(L.urn_rows_scatter_add(_l.ptr(dy), ctx.idx.data_ptr(), n_rows, c, dx.data_ptr(), _l.stream()),
                  'rows_scatter_add')
         return dx, None, None
+
+
+class HeadFunction(torch.autograd.Function):
+    """logits = rows @ W^T + b on the HIP head kernel (identity row map: the trunk already applied OutputLayer)."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias):
+        _l.require_gpu(rows)
+        L = _l.load()
+        rows = rows.contiguous(); weight = weight.contiguous()
+        n, m = rows.shape
+        nc = weight.shape[0]
+        logits = torch.empty((n, nc), dtype=torch.float32, device=rows.device)
+        _l.check(L.urn_head_fwd(rows.data_ptr(), None, n, m, nc, weight.data_ptr(), _l.ptr(bias), logits.data_ptr(),
+                                _l.stream()), 'head_fwd')
+        ctx.save_for_backward(rows, weight)
+        ctx.has_bias = bias is not None
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        rows, weight = ctx.saved_tensors
+        L = _l.load()
+        n, m = rows.shape
+        nc = weight.shape[0]
+        dl = dl.contiguous()
+        dx = torch.empty_like(rows)
+        dW = torch.zeros_like(weight)
+        db = torch.zeros(nc, dtype=torch.float32, device=rows.device)
+        _l.check(L.urn_head_bwd(dl.data_ptr(), rows.data_ptr(), None, n, m, nc, weight.data_ptr(), dx.data_ptr(),
+                                dW.data_ptr(), db.data_ptr(), _l.stream()), 'head_bwd')
+        return dx, dW, (db if ctx.has_bias else None)
+
+
+class SegmentationCEFunction(torch.autograd.Function):
+    """sum over events of the mean (weighted) voxel cross-entropy; also returns the summed per-event accuracy.
+    One pass over the rows, per-event sums on the device, no host synchronisation."""
+
+    @staticmethod
+    def forward(ctx, logits, data, label, weight):
+        _l.require_gpu(logits)
+        L = _l.load()
+        logits = logits.contiguous()
+        n, nc = logits.shape
+        assert data.is_contiguous() and data.dtype == torch.float32 and label.dtype == torch.float32
+        label = label.contiguous()
+        w = None if weight is None else weight.contiguous().float()
+        stride = data.shape[1]
+        bid_ptr = data.data_ptr() + 4 * (stride - 2)            # column -2 = batch id (reference :57)
+        row_lse = torch.empty(n, dtype=torch.float32, device=logits.device)
+        ev = torch.empty(L.urn_ce_scratch_bytes() // 8, dtype=torch.float64, device=logits.device)
+        out = torch.empty(2, dtype=torch.float32, device=logits.device)
+        _l.check(L.urn_ce_fwd(logits.data_ptr(), label.data_ptr(), bid_ptr, stride, _l.ptr(w), n, nc, row_lse.data_ptr(),
+                              ev.data_ptr(), out.data_ptr(), _l.stream()), 'ce_fwd')
+        ctx.save_for_backward(logits, data, label, row_lse, ev)
+        ctx.w = w
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+    
+    @staticmethod
+    def backward(ctx, gloss, _gout):
+        logits, data, label, row_lse, ev = ctx.saved_tensors
+        L = _l.load()
+        n, nc = logits.shape
+        stride = data.shape[1]
+        g = gloss.contiguous().float().reshape(1)
+        dl = torch.empty_like(logits)
+        _l.check(L.urn_ce_bwd(logits.data_ptr(), label.data_ptr(), data.data_ptr() + 4 * (stride - 2), stride,
+                              _l.ptr(ctx.w), row_lse.data_ptr(), ev.data_ptr(), g.data_ptr(), n, nc, dl.data_ptr(),
+                              _l.stream()), 'ce_bwd')
+        return dl, None, None, None

@@ -150,7 +150,7 @@ class trainval(object):
             self._net.eval()
         self._criterion.to(self._device)
 
-        self._optimizer = torch.optim.Adam(self._net.parameters(), lr=self._flags.LEARNING_RATE)
+        self._optimizer = torch.optim.Adam(self._net.parameters(), lr=self._flags.LEARNING_RATE, fused=use_gpu)
         self._softmax = torch.nn.Softmax(dim=1 if 'sparse' in self._flags.MODEL_NAME else 0)
 
         iteration = 0
