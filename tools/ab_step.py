@@ -15,7 +15,9 @@ blob = make_sparse_blob([0], 512, 50000)
 data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
 crit = SparseSegmentationLoss(flags)
 variants = {}
-for name, fl in (('fused+side', 0), ('unfused+side', 1), ('fused+single', 2), ('unfused+single', 3)):
+from uresnet_pytorch_amd import lib as _lib
+L = _lib.load()
+for name, fl in (('fused+side', 0), ('unfused+side', 1)):
     torch.manual_seed(0)
     net = SparseUResNet(flags).to(dev).train(); net.executor_flags = fl
     g = parallel.FlatGradients(net); opt = torch.optim.Adam(net.parameters(), lr=1e-3)
@@ -25,10 +27,15 @@ for name, fl in (('fused+side', 0), ('unfused+side', 1), ('fused+single', 2), ('
 for s in variants.values():
     for _ in range(5): s()
 res = {k: [] for k in variants}
-for rnd in range(5):
-    for k, s in variants.items():
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(20): s()
-        torch.cuda.synchronize(); res[k].append((time.perf_counter() - t0) / 20 * 1e3)
+kernels = {'tile2d(6)': 6, 'lds64x16(4)': 4, 'reg(3)': 3}
+res = {(k, kn): [] for k in variants for kn in kernels}
+for rnd in range(4):
+    for kn, kv in kernels.items():
+        L.urn_set_option(b'gconv_kernel', kv)
+        for k, s in variants.items():
+            for _ in range(2): s()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(20): s()
+            torch.cuda.synchronize(); res[(k, kn)].append((time.perf_counter() - t0) / 20 * 1e3)
 for k, v in res.items():
-    print('%-16s median %.3f ms  min %.3f ms' % (k, float(np.median(v)), min(v)))
+    print('%-28s median %.3f ms  min %.3f ms' % (str(k), float(np.median(v)), min(v)))

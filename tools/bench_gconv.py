@@ -21,11 +21,11 @@ def run(level, cin, cout, reps=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 shapes = [(0, 16, 16), (1, 32, 32), (2, 48, 48), (3, 64, 64), (4, 80, 80), (3, 128, 64), (2, 96, 48)]
-variants = [('full', 0), ('noMFMA', 1), ('noA', 2), ('noB', 4), ('noAB', 6), ('noBar', 8), ('noOffsets', 16), ('noMFMA,A,B', 7)]
+variants = [('lds64x16', 4), ('tile2d', 6)]
 for lv, ci, co in shapes:
     out = []
     for name, mw in variants:
-        L.urn_set_option(b'gconv_kernel', 4); L.urn_set_option(b'gconv_dbg', mw)
+        L.urn_set_option(b'gconv_kernel', mw); L.urn_set_option(b'gconv_dbg', 0)
         t = min(run(lv, ci, co) for _ in range(3))
         out.append('%s %.1f' % (name, t))
     fl = 2.0 * geo.rules[lv] * ci * co

@@ -256,7 +256,7 @@ extern long g_lds_min_wgs;
 static int g_opt_dbg = 0;
 static int g_opt_fin_in_kernel = 0;
 static int g_opt_pipe = 0;
-static int g_opt_kernel = 4;   // 4 = LDS-staged tile kernel (urn_gconv_lds.hip), 3 = register-gather kernel below
+static int g_opt_kernel = 6;   // 6 = 2-D workgroup tile (urn_gconv_tile.hip), 4 = 64x16 LDS tile (urn_gconv_lds.hip), 5 = LDS-DMA ring, 3 = register gather
 static long g_opt_min_waves = 8192;
 
 extern "C" int urn_set_option(const char *key, int64_t value)
@@ -381,6 +381,16 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_GCONV, st);
     bool ok = false;
+    if (g_opt_kernel == 6 && !in_kernel) {
+        const int np6 = urn_gconv_tile_launch(a, ks, u->n_out, st);
+        if (np6 > 0) {
+            if (prof) urn_prof_end(st);
+            if (n_tiles) *n_tiles = np6;
+            URN_LAUNCH_CHECK();
+            if (want_fin) return finalize_launches(u, np6, stream);
+            return URN_OK;
+        }
+    }
     if ((g_opt_kernel == 5 && urn_gconv_dma_launch(a, ks, u->n_out, st)) ||
         (g_opt_kernel >= 4 && urn_gconv_lds_launch(a, ks, u->n_out, st))) {
         if (prof) urn_prof_end(st);

@@ -30,5 +30,7 @@ struct GArgs {
 
 // LDS-staged variant (urn_gconv_lds.hip): returns false when it has no instantiation for the shape
 bool urn_gconv_lds_launch(const GArgs &a, int ks, long n_out, hipStream_t st);
+// 2-D workgroup tile (urn_gconv_tile.hip): returns the number of partial rows, 0 = no instantiation
+int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st);
 // LDS-DMA ring variant (urn_gconv_dma.hip)
 bool urn_gconv_dma_launch(const GArgs &a, int ks, long n_out, hipStream_t st);

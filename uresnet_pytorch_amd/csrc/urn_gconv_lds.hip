@@ -21,7 +21,7 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int KS, int NB>
+template <int KS, int NB, int STAMP = 0>
 __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
 {
     constexpr int CIN = KS * 16;
@@ -123,12 +123,21 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
         m &= m - 1u;
         return t;
     };
+    unsigned long long st_frag = 0, st_fetch = 0, st_mfma = 0, st_park = 0, st_bar = 0, st_n = 0;   // STAMP build only
     // one pipeline step: fragments of offset tc out of LDS, global fetch of the offset three ahead, MFMAs of tc,
     // then park the next offset (fetched two steps ago) into the free LDS buffers; one barrier per step
     auto step = [&](int tc, int buf, f32x4 (&ra_n)[A_F4], f32x4 (&rb_n)[B_F4], int tn, f32x4 (&ra_f)[A_F4],
                     f32x4 (&rb_f)[B_F4], int tf) {
         const bool act = (amask >> tc) & 1u;  // wave-uniform
         f32x4 fa[KS], fb[KS][NB];
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+#define URN_STAMP(v)                                                                          \
+    if (STAMP) {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    }
+        URN_STAMP(c0)
         if (act) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -137,7 +146,9 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
                 for (int nb = 0; nb < NB; ++nb) fb[ks][nb] = *(const f32x4 *)&s_b[buf][nb * 16 + r][ks * 16 + 4 * q];
             }
         }
+        URN_STAMP(c1)     // fragment reads landed (the stamp waits lgkmcnt(0))
         fetch(ra_f, rb_f, tf);
+        URN_STAMP(c2)     // global fetch of the offset three ahead issued
         if (act && !(g.dbg & 1)) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
@@ -146,12 +157,17 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) acc[nb] = MFMA16(fa[ks][tt], fb[ks][nb][tt], acc[nb]);
         }
+        URN_STAMP(c3)     // MFMAs issued
         park(ra_n, rb_n, tn, buf ^ 1);   // s_a[wave] is private and its fragments are already in registers
         // The barrier only orders LDS traffic.  __syncthreads() would also wait for vmcnt(0) -- on gfx950 loads and
         // stores share that counter -- and drain the two offsets of global prefetch every step.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        URN_STAMP(c4)     // next offset parked (includes the wait for its global data)
         if (!(g.dbg & 8)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        URN_STAMP(c5)     // barrier passed
+#undef URN_STAMP
+        if (STAMP) { st_frag += c1 - c0; st_fetch += c2 - c1; st_mfma += c3 - c2; st_park += c4 - c3; st_bar += c5 - c4; st_n += 1; }
     };
 
     // 2. offset loop, unrolled by three so that every register set has a static name
@@ -172,6 +188,14 @@ __global__ __launch_bounds__(256) void k_gconv_lds(GArgs g)
         t0 = t3; t1 = t4; t2 = t5;
     }
 
+    if (STAMP) {   // diagnostic build: per-workgroup cycle sums of wave 0 into the (otherwise unused) partial slab
+        if (tid == 0 && g.part) {
+            double *o = g.part + (long)blockIdx.x * 8;
+            o[0] = (double)st_frag; o[1] = (double)st_fetch; o[2] = (double)st_mfma; o[3] = (double)st_park;
+            o[4] = (double)st_bar; o[5] = (double)st_n;
+        }
+        return;
+    }
     // 3. epilogue (per 16-row block).  C layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
     double s0[NB], s1[NB];
 #pragma unroll
@@ -313,6 +337,12 @@ static bool launch_lds_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
         const long lds = 7168 + 4L * 16 * (KS * 16 + 4) * 4 + 2L * d * 16 * (KS * 16 + 4) * 4;
         if (lds > 65536) continue;
         if (blocks * (nblk / d) >= g_lds_min_wgs) { nb = d; break; }
+    }
+    if ((a.dbg & 32) && a.part) {   // diagnostic stamp build (KS = 4 only)
+        if constexpr (KS == 4) {
+            hipLaunchKernelGGL((k_gconv_lds<4, 1, 1>), dim3((unsigned)blocks, a.cout / 16), dim3(256), 0, st, a);
+            return true;
+        }
     }
     if (nb == 4) { if constexpr (KS <= 6) { launch_lds<KS, 4>(a, n_out, st); return true; } nb = 2; }
     if (nb == 3) { if constexpr (KS <= 8) { launch_lds<KS, 3>(a, n_out, st); return true; } nb = 1; }

@@ -1,0 +1,227 @@
+// Gather convolution, 2-D workgroup tile: RB row blocks x CB column blocks of 16x16 outputs, one wave each.
+//
+// In-kernel cycle stamps on the 64x16 tile kernel (urn_gconv_lds.hip) showed ~80% of an offset step in
+// issuing the gathers and waiting for them: the step is bound by the per-CU gather rate (~23 B/clk/CU
+// measured, MI355X_MICROARCH.md "Indexed rows: gather into LDS" gives 14-30 B/clk/CU), and that tile moves
+// A + B/4 operand bytes per wave-step.  Here the RB*CB waves of a workgroup share BOTH operands through
+// LDS: the 16*RB gathered rows are fetched once for the CB column blocks, the CB*16-column weight tile once
+// for the RB row blocks, i.e. A/CB + B/RB bytes per wave-step, with the same number of waves on the chip.
+// Arithmetic, determinism, epilogues and the partial-slab layout (one row per workgroup) are unchanged.
+#include "urn_common.h"
+#include "urn_gconv_int.h"
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int KS, int RB, int CB>
+__global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
+{
+    constexpr int CIN = KS * 16;
+    constexpr int LDA = CIN + 4;
+    constexpr int T = 64 * RB * CB;                                 // threads
+    constexpr int A_TOT = RB * 16 * CIN / 4, B_TOT = CB * 16 * CIN / 4;   // float4 per operand tile
+    constexpr int A_F4 = (A_TOT + T - 1) / T, B_F4 = (B_TOT + T - 1) / T;
+    __shared__ int s_idx[RB][28 * 16];
+    __shared__ unsigned s_mask[RB];
+    __shared__ float s_xf[2][CIN];
+    __shared__ __attribute__((aligned(16))) float s_a[2][RB * 16][LDA];
+    __shared__ __attribute__((aligned(16))) float s_b[2][CB * 16][LDA];
+    __shared__ double s_p[2][RB][CB * 16];
+
+    const long n_out = g.n_dev ? (long)*g.n_dev : g.n_cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = wave / CB, cb = wave - rb * CB;
+    const int r = lane & 15, q = lane >> 4;
+    const long row_base = ((long)blockIdx.x * RB + rb) * 16;
+    const long tile_row0 = (long)blockIdx.x * RB * 16;
+    const int col_base = (blockIdx.y * CB + cb) * 16;
+    const int tile_col0 = blockIdx.y * CB * 16;
+    const int K = g.K, cout = g.cout;
+    const bool xf = g.xf_scale != nullptr;
+
+    // 1. table fetch (the cb == 0 wave of every row block), masks
+    if (cb == 0) {
+        unsigned amask = 0u;
+        const long row = row_base + r;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int t = 4 * i + q;
+            int v = -1;
+            if (t < K && row < n_out) v = g.tbl[(long)t * g.ld + row];
+            s_idx[rb][i * 64 + lane] = v;  // == [t][r]
+            const unsigned long long b = __ballot(v >= 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((b >> (16 * j)) & 0xFFFFull) amask |= 1u << (4 * i + j);
+        }
+        if (lane == 0) s_mask[rb] = amask;
+    }
+    if (xf)
+        for (int e = tid; e < CIN; e += T) { s_xf[0][e] = g.xf_scale[e]; s_xf[1][e] = g.xf_shift[e]; }
+    __syncthreads();
+    unsigned m = 0u;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) m |= s_mask[i];
+    const unsigned my_mask = s_mask[rb];
+    if (g.dbg & 16) m = 0u;
+
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[A_F4], rb_[B_F4];
+    auto fetch = [&](int t) {
+        const int o = g.flip ? (K - 1 - t) : t;
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int e = j * T + tid;
+            if (A_TOT % T == 0 || e < A_TOT) {
+                const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
+                const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
+                ra[j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * CIN + 4 * c4);
+            }
+        }
+        const float *wo = g.wt + ((long)o * cout + tile_col0) * CIN;
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) {
+            const int e = j * T + tid;
+            if (B_TOT % T == 0 || e < B_TOT) rb_[j] = *(const f32x4 *)(wo + 4 * (long)e);
+        }
+    };
+    auto park = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int e = j * T + tid;
+            if (A_TOT % T == 0 || e < A_TOT) {
+                const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
+                const bool have = s_idx[row >> 4][t * 16 + (row & 15)] >= 0;
+                f32x4 v = ra[j];
+                if (xf) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], s_xf[0][4 * c4 + k], s_xf[1][4 * c4 + k]), 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = have ? v[k] : 0.f;
+                *(f32x4 *)&s_a[buf][row][4 * c4] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) {
+            const int e = j * T + tid;
+            if (B_TOT % T == 0 || e < B_TOT) {
+                const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
+                *(f32x4 *)&s_b[buf][col][4 * c4] = rb_[j];
+            }
+        }
+    };
+
+    // 2. offset loop: fetch(i+1) in flight during the MFMAs of i; one LDS-only barrier per offset
+    int t_cur = -1, buf = 0;
+    if (m) { t_cur = __builtin_ctz(m); m &= m - 1u; fetch(t_cur); park(t_cur, 0); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    while (t_cur >= 0) {
+        int t_next = -1;
+        if (m) { t_next = __builtin_ctz(m); m &= m - 1u; fetch(t_next); }
+        if ((my_mask >> t_cur) & 1u) {  // wave-uniform: this row block has neighbours at the offset
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f32x4 a = *(const f32x4 *)&s_a[buf][rb * 16 + r][ks * 16 + 4 * q];
+                const f32x4 b = *(const f32x4 *)&s_b[buf][cb * 16 + r][ks * 16 + 4 * q];
+                if (ks & 1) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc2 = MFMA16(a[tt], b[tt], acc2);
+                } else {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc = MFMA16(a[tt], b[tt], acc);
+                }
+            }
+        }
+        if (t_next >= 0) park(t_next, buf ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        t_cur = t_next;
+        buf ^= 1;
+    }
+
+    // 3. epilogue: one 16x16 block per wave.  C layout: col = lane&15, row = (lane>>4)*4 + reg
+    double s0 = 0.0, s1 = 0.0;
+    {
+        const int col = col_base + r;
+        float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
+        if (g.epi == 2) { esc = g.e_scale[col]; esh = g.e_shift[col]; emu = g.e_mean[col]; eis = g.e_invstd[col]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = row_base + q * 4 + i;
+            if (row >= n_out) continue;
+            const long off = row * cout + col;
+            float v = acc[i] + acc2[i];
+            if (g.res) v += g.res[off];
+            if (g.epi == 1) {
+                s0 += (double)v;
+                s1 += (double)v * (double)v;
+            } else if (g.epi == 2) {
+                const float xv = g.e_x[off];
+                if (!(fmaf(xv, esc, esh) > 0.f)) v = 0.f;
+                const double xh = ((double)xv - (double)emu) * (double)eis;
+                s0 += (double)v;
+                s1 += (double)v * xh;
+            }
+            g.y[off] = v;
+        }
+    }
+    if (g.epi == 0) return;
+    s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
+    s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
+    if (q == 0) { s_p[0][rb][cb * 16 + r] = s0; s_p[1][rb][cb * 16 + r] = s1; }
+    __syncthreads();
+    if (tid < CB * 16) {
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) { v0 += s_p[0][i][tid]; v1 += s_p[1][i][tid]; }
+        g.part[((long)blockIdx.x * 2 + 0) * cout + tile_col0 + tid] = v0;
+        g.part[((long)blockIdx.x * 2 + 1) * cout + tile_col0 + tid] = v1;
+    }
+    (void)tile_row0;
+}
+
+template <int KS, int RB, int CB>
+static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
+{
+    const long bx = (n_out + 16 * RB - 1) / (16 * RB);
+    hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB>), dim3((unsigned)bx, a.cout / (16 * CB)), dim3(64 * RB * CB), 0, st, a);
+    return (int)bx;
+}
+
+// returns the number of partial rows (workgroups along the rows), 0 when the shape has no instantiation
+template <int KS>
+static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
+{
+    const long blocks16 = (n_out + 15) / 16;
+    // column blocks per workgroup: all of them up to 5; row blocks: as many as keep >= ~256 workgroups, <= 16 waves
+    int cb = nblk <= 5 ? nblk : (nblk % 4 == 0 ? 4 : (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 1)));
+    int rb = 1;
+    for (int cand : {4, 2}) {
+        if (cand * cb > 16) continue;
+        if ((blocks16 / cand) * (nblk / cb) >= 256) { rb = cand; break; }
+    }
+    if (KS * (rb + 2 * cb) > 60) return 0;   // LDS: (2*RB + 2*CB)*16*(CIN+4)*4 bytes must stay small
+#define URN_TL(RBv, CBv) if (rb == RBv && cb == CBv) return launch_tile2<KS, RBv, CBv>(a, n_out, st);
+    URN_TL(1, 1) URN_TL(2, 1) URN_TL(4, 1) URN_TL(1, 2) URN_TL(2, 2) URN_TL(4, 2) URN_TL(1, 3) URN_TL(2, 3) URN_TL(4, 3)
+    URN_TL(1, 4) URN_TL(2, 4) URN_TL(4, 4) URN_TL(1, 5) URN_TL(2, 5)
+#undef URN_TL
+    return 0;
+}
+
+int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st)
+{
+    const int nblk = a.cout / 16;
+    switch (ks) {
+    case 1: return launch_tile_ks<1>(a, n_out, nblk, st);
+    case 2: return launch_tile_ks<2>(a, n_out, nblk, st);
+    case 3: return launch_tile_ks<3>(a, n_out, nblk, st);
+    case 4: return launch_tile_ks<4>(a, n_out, nblk, st);
+    case 5: return launch_tile_ks<5>(a, n_out, nblk, st);
+    case 6: return launch_tile_ks<6>(a, n_out, nblk, st);
+    case 8: return launch_tile_ks<8>(a, n_out, nblk, st);
+    default: return 0;
+    }
+}
