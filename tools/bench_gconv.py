@@ -20,13 +20,15 @@ def run(level, cin, cout, reps=30):
     for _ in range(reps): call()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-shapes = [(0, 16, 16), (1, 32, 32), (2, 48, 48), (3, 64, 64), (4, 80, 80), (3, 128, 64), (2, 96, 48)]
-variants = [('lds64x16', 4), ('tile2d', 6)]
+shapes = [(0, 16, 16), (1, 32, 32), (2, 48, 48), (3, 64, 64), (4, 80, 80), (3, 128, 64), (2, 96, 48), (1, 64, 32), (0, 32, 16), (1, 16, 32), (2, 32, 48), (3, 48, 64), (4, 64, 80)]
+variants = [('auto', (0, 0)), ('1x1', (1, 1)), ('2x1', (2, 1)), ('4x1', (4, 1)), ('1x2', (1, 2)), ('2x2', (2, 2)), ('4x2', (4, 2)), ('1x3', (1, 3)), ('2x3', (2, 3)), ('4x3', (4, 3)), ('1x4', (1, 4)), ('2x4', (2, 4)), ('4x4', (4, 4)), ('1x5', (1, 5)), ('2x5', (2, 5))]
 for lv, ci, co in shapes:
     out = []
     for name, mw in variants:
-        L.urn_set_option(b'gconv_kernel', mw); L.urn_set_option(b'gconv_dbg', 0)
+        L.urn_set_option(b'gconv_kernel', 6); L.urn_set_option(b'tile_rb', mw[0]); L.urn_set_option(b'tile_cb', mw[1])
+        if mw[1] and (co // 16) % mw[1]:
+            continue
         t = min(run(lv, ci, co) for _ in range(3))
-        out.append('%s %.1f' % (name, t))
+        out.append('%s %.0f' % (name, t))
     fl = 2.0 * geo.rules[lv] * ci * co
-    print('L%d %3d->%3d  n=%6d  %s   [useful %.2f GF]' % (lv, ci, co, geo.n[lv], ' | '.join(out), fl / 1e9))
+    print('L%d %3d->%3d n=%6d %s' % (lv, ci, co, geo.n[lv], ' | '.join(out)))

@@ -191,19 +191,31 @@ static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
     return (int)bx;
 }
 
+int g_tile_rb = 0, g_tile_cb = 0;   // tuning knobs (urn_set_option "tile_rb" / "tile_cb"), 0 = automatic
+
 // returns the number of partial rows (workgroups along the rows), 0 when the shape has no instantiation
 template <int KS>
 static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
 {
     const long blocks16 = (n_out + 15) / 16;
-    // column blocks per workgroup: all of them up to 5; row blocks: as many as keep >= ~256 workgroups, <= 16 waves
-    int cb = nblk <= 5 ? nblk : (nblk % 4 == 0 ? 4 : (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 1)));
-    int rb = 1;
-    for (int cand : {4, 2}) {
-        if (cand * cb > 16) continue;
-        if ((blocks16 / cand) * (nblk / cb) >= 256) { rb = cand; break; }
+    // Tile choice (measured sweep on MI355X, tools/bench_gconv.py): take all column blocks when there are <= 5 (the
+    // gathered rows are then fetched once), as many row blocks as still leave >= ~100 workgroups, at most 16 waves,
+    // and an LDS image (2 A + 2 B buffers) under 96 KiB.
+    auto lds_ok = [&](int rb_, int cb_) { return (long)(rb_ + cb_) * 128 * (KS * 16 + 4) <= 98304 && rb_ * cb_ <= 16; };
+    int rb = 0, cb = 0;
+    for (int c = (nblk <= 5 ? nblk : 4); c >= 1 && !rb; --c) {
+        if (nblk % c) continue;
+        for (int cand : {4, 2, 1}) {
+            if (!lds_ok(cand, c)) continue;
+            if (cand > 1 && (blocks16 / cand) * (nblk / c) < 100) continue;
+            rb = cand; cb = c;
+            break;
+        }
     }
-    if (KS * (rb + 2 * cb) > 60) return 0;   // LDS: (2*RB + 2*CB)*16*(CIN+4)*4 bytes must stay small
+    if (!rb) return 0;
+    if (g_tile_rb > 0) rb = g_tile_rb;
+    if (g_tile_cb > 0 && nblk % g_tile_cb == 0) cb = g_tile_cb;
+    if (!lds_ok(rb, cb)) return 0;
 #define URN_TL(RBv, CBv) if (rb == RBv && cb == CBv) return launch_tile2<KS, RBv, CBv>(a, n_out, st);
     URN_TL(1, 1) URN_TL(2, 1) URN_TL(4, 1) URN_TL(1, 2) URN_TL(2, 2) URN_TL(4, 2) URN_TL(1, 3) URN_TL(2, 3) URN_TL(4, 3)
     URN_TL(1, 4) URN_TL(2, 4) URN_TL(4, 4) URN_TL(1, 5) URN_TL(2, 5)
