@@ -164,9 +164,9 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
         if os.path.exists(tpath):
-            traffic = round(json.load(open(tpath)).get('k_gconv_lds_traffic_bytes_per_launch', 0.0)) or None
+            traffic = round(json.load(open(tpath)).get('gconv_traffic_bytes_per_launch', 0.0)) or None
         roofline = {
-            'bound': 'mfma', 'kernel': 'k_gconv_lds<KS,NB> (gather-conv forward + input-gradient)',
+            'bound': 'mfma', 'kernel': 'k_gconv_tile<KS,RB,CB> (gather-conv forward + input-gradient)',
             'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic,
             'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)',

@@ -201,7 +201,7 @@ static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
     // Tile choice (measured sweep on MI355X, tools/bench_gconv.py): take all column blocks when there are <= 5 (the
     // gathered rows are then fetched once), as many row blocks as still leave >= ~100 workgroups, at most 16 waves,
     // and an LDS image (2 A + 2 B buffers) under 96 KiB.
-    auto lds_ok = [&](int rb_, int cb_) { return (long)(rb_ + cb_) * 128 * (KS * 16 + 4) <= 98304 && rb_ * cb_ <= 16; };
+    auto lds_ok = [&](int rb_, int cb_) { return (long)(rb_ + cb_) * 128 * (KS * 16 + 4) <= 98304 && rb_ * cb_ <= 12; };   // 16-wave (1024-thread) workgroups measured 1.5x slower
     int rb = 0, cb = 0;
     for (int c = (nblk <= 5 ? nblk : 4); c >= 1 && !rb; --c) {
         if (nblk % c) continue;
