@@ -12,7 +12,7 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int KS, int RB, int CB>
+template <int KS, int RB, int CB, int G>
 __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 {
     constexpr int CIN = KS * 16;
@@ -23,8 +23,8 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     __shared__ int s_idx[RB][28 * 16];
     __shared__ unsigned s_mask[RB];
     __shared__ float s_xf[2][CIN];
-    __shared__ __attribute__((aligned(16))) float s_a[2][RB * 16][LDA];
-    __shared__ __attribute__((aligned(16))) float s_b[2][CB * 16][LDA];
+    __shared__ __attribute__((aligned(16))) float s_a[2][G][RB * 16][LDA];   // G filter offsets per step
+    __shared__ __attribute__((aligned(16))) float s_b[2][G][CB * 16][LDA];
     __shared__ double s_p[2][RB][CB * 16];
 
     const long n_out = g.n_dev ? (long)*g.n_dev : g.n_cap;
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     if (g.dbg & 16) m = 0u;
 
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[A_F4], rb_[B_F4];
-    auto fetch = [&](int t) {
+    f32x4 ra[G][A_F4], rb_[G][B_F4];
+    auto fetch = [&](int t, int gi) {
         const int o = g.flip ? (K - 1 - t) : t;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
@@ -74,31 +74,31 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             if (A_TOT % T == 0 || e < A_TOT) {
                 const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
                 const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
-                ra[j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * CIN + 4 * c4);
+                ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * CIN + 4 * c4);
             }
         }
         const float *wo = g.wt + ((long)o * cout + tile_col0) * CIN;
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             const int e = j * T + tid;
-            if (B_TOT % T == 0 || e < B_TOT) rb_[j] = *(const f32x4 *)(wo + 4 * (long)e);
+            if (B_TOT % T == 0 || e < B_TOT) rb_[gi][j] = *(const f32x4 *)(wo + 4 * (long)e);
         }
     };
-    auto park = [&](int t, int buf) {
+    auto park = [&](int t, int buf, int gi) {
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
             const int e = j * T + tid;
             if (A_TOT % T == 0 || e < A_TOT) {
                 const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
                 const bool have = s_idx[row >> 4][t * 16 + (row & 15)] >= 0;
-                f32x4 v = ra[j];
+                f32x4 v = ra[gi][j];
                 if (xf) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], s_xf[0][4 * c4 + k], s_xf[1][4 * c4 + k]), 0.f);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = have ? v[k] : 0.f;
-                *(f32x4 *)&s_a[buf][row][4 * c4] = v;
+                *(f32x4 *)&s_a[buf][gi][row][4 * c4] = v;
             }
         }
 #pragma unroll
@@ -106,26 +106,48 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             const int e = j * T + tid;
             if (B_TOT % T == 0 || e < B_TOT) {
                 const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
-                *(f32x4 *)&s_b[buf][col][4 * c4] = rb_[j];
+                *(f32x4 *)&s_b[buf][gi][col][4 * c4] = rb_[gi][j];
             }
         }
     };
 
-    // 2. offset loop: fetch(i+1) in flight during the MFMAs of i; one LDS-only barrier per offset
-    int t_cur = -1, buf = 0;
-    if (m) { t_cur = __builtin_ctz(m); m &= m - 1u; fetch(t_cur); park(t_cur, 0); }
+    // 2. offset loop, G active offsets per step (a step with one 16..64-channel offset is too thin to cover a
+    //    memory round trip: 4*KS MFMAs per wave): the next group's loads are in flight during the MFMAs of the
+    //    current one; one LDS-only barrier per step
+    int tc[G], tn[G];
+    auto take = [&](int (&ts)[G]) -> int {
+        int cnt = 0;
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            ts[gi] = -1;
+            if (m) { ts[gi] = __builtin_ctz(m); m &= m - 1u; ++cnt; }
+        }
+        return cnt;
+    };
+    int buf = 0;
+    int n_cur = take(tc);
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+        if (tc[gi] >= 0) fetch(tc[gi], gi);
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+        if (tc[gi] >= 0) park(tc[gi], 0, gi);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    while (t_cur >= 0) {
-        int t_next = -1;
-        if (m) { t_next = __builtin_ctz(m); m &= m - 1u; fetch(t_next); }
-        if ((my_mask >> t_cur) & 1u) {  // wave-uniform: this row block has neighbours at the offset
+    while (n_cur > 0) {
+        const int n_next = take(tn);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi)
+            if (tn[gi] >= 0) fetch(tn[gi], gi);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            if (tc[gi] < 0 || !((my_mask >> tc[gi]) & 1u)) continue;  // wave-uniform
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const f32x4 a = *(const f32x4 *)&s_a[buf][rb * 16 + r][ks * 16 + 4 * q];
-                const f32x4 b = *(const f32x4 *)&s_b[buf][cb * 16 + r][ks * 16 + 4 * q];
-                if (ks & 1) {
+                const f32x4 a = *(const f32x4 *)&s_a[buf][gi][rb * 16 + r][ks * 16 + 4 * q];
+                const f32x4 b = *(const f32x4 *)&s_b[buf][gi][cb * 16 + r][ks * 16 + 4 * q];
+                if ((ks + gi) & 1) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) acc2 = MFMA16(a[tt], b[tt], acc2);
                 } else {
@@ -134,11 +156,15 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
                 }
             }
         }
-        if (t_next >= 0) park(t_next, buf ^ 1);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi)
+            if (tn[gi] >= 0) park(tn[gi], buf ^ 1, gi);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        t_cur = t_next;
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) tc[gi] = tn[gi];
+        n_cur = n_next;
         buf ^= 1;
     }
 
@@ -183,11 +209,20 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     (void)tile_row0;
 }
 
+// offsets per step.  Grouping several thin offsets into one step (G = 4 at 16 channels, 2 up to 64) was measured
+// and did not pay (cfg3 step 4.93 vs 4.56 ms: the larger LDS image costs occupancy), so G stays 1.
+template <int KS, int RB, int CB>
+constexpr int tile_group()
+{
+    return 1;
+}
+
 template <int KS, int RB, int CB>
 static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
 {
     const long bx = (n_out + 16 * RB - 1) / (16 * RB);
-    hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB>), dim3((unsigned)bx, a.cout / (16 * CB)), dim3(64 * RB * CB), 0, st, a);
+    constexpr int G = tile_group<KS, RB, CB>();
+    hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, G>), dim3((unsigned)bx, a.cout / (16 * CB)), dim3(64 * RB * CB), 0, st, a);
     return (int)bx;
 }
 
