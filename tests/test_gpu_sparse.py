@@ -89,7 +89,8 @@ def test_integer_phase_full_size(dev):
     assert geo.n[0] == 50000
 
 
-CONV_SHAPES = [(1, 16), (16, 16), (16, 32), (32, 48), (80, 80), (128, 64), (96, 48)]
+CONV_SHAPES = [(1, 16), (16, 16), (16, 32), (32, 48), (80, 80), (128, 64), (96, 48),
+               (384, 192), (224, 224), (352, 176)]   # cfg5 widths: input channels walked in chunks
 
 
 @pytest.mark.parametrize('cin,cout', CONV_SHAPES)

@@ -345,8 +345,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     URN_CHECK_ARG(u->epilogue != 2 || (u->e_x && u->e_scale && u->e_shift && u->e_mean && u->e_invstd), "epilogue 2 needs the BatchNorm inputs");
     hipStream_t st = (hipStream_t)stream;
     const int ks = u->cin / 16;
-    const bool mfma_ok = (u->cin % 16 == 0) && (u->cout % 16 == 0) && u->K <= 28 &&
-                         (ks <= 6 || ks == 8 || ks == 10 || ks == 12 || ks == 14);
+    const bool mfma_ok = (u->cin % 16 == 0) && (u->cout % 16 == 0) && u->K <= 28;
     if (!mfma_ok) {
         if (u->xf_scale || u->epilogue) { urn_set_error("urn_gconv_fwd_ex: fusions need channel counts that are multiples of 16"); return URN_EUNSUPPORTED; }
         hipLaunchKernelGGL(k_gconv_small, dim3(urn_cdiv(u->n_out * u->cout, 256)), dim3(256), 0, st, u->x, u->wt, u->tbl,
@@ -364,7 +363,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     GArgs a;
     memset(&a, 0, sizeof(a));
     a.x = u->x; a.wt = u->wt; a.tbl = u->tbl; a.ld = (long)u->ld; a.K = u->K; a.flip = u->flip; a.n_cap = (long)u->n_out;
-    a.cout = u->cout; a.res = u->res; a.y = u->y; a.xf_scale = u->xf_scale; a.xf_shift = u->xf_shift; a.epi = u->epilogue;
+    a.cout = u->cout; a.cin = u->cin; a.res = u->res; a.y = u->y; a.xf_scale = u->xf_scale; a.xf_shift = u->xf_shift; a.epi = u->epilogue;
     a.part = u->part; a.e_x = u->e_x; a.e_scale = u->e_scale; a.e_shift = u->e_shift; a.e_mean = u->e_mean;
     a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg;
     // finalize requested?  In-kernel (last workgroup) only on request: measured on MI355X the tail work (every
@@ -414,7 +413,8 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     case 8: ok = launch_ks<8>(a, u->n_out, p, split, st); break;
     case 10: ok = launch_ks<10>(a, u->n_out, p, split, st); break;
     case 12: ok = launch_ks<12>(a, u->n_out, p, split, st); break;
-    default: ok = launch_ks<14>(a, u->n_out, p, split, st); break;
+    case 14: ok = launch_ks<14>(a, u->n_out, p, split, st); break;
+    default: ok = false; break;
     }
     if (prof) urn_prof_end(st);
     if (!ok) { urn_set_error("urn_gconv_fwd_ex: no kernel for cin=%d tile %dx%d", u->cin, p.mb, p.nb); return URN_EUNSUPPORTED; }

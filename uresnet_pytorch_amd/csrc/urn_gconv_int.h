@@ -10,6 +10,7 @@ struct GArgs {
     const int *n_dev;
     long n_cap;
     int cout;
+    int cin;   // total input channels (the tile kernel walks them in chunks of KS*16)
     const float *res;
     float *y;
     const float *xf_scale, *xf_shift;

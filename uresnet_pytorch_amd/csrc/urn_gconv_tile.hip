@@ -15,14 +15,14 @@
 template <int KS, int RB, int CB, int G>
 __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 {
-    constexpr int CIN = KS * 16;
+    constexpr int CIN = KS * 16;                                    // channels per step (a chunk of g.cin)
     constexpr int LDA = CIN + 4;
     constexpr int T = 64 * RB * CB;                                 // threads
     constexpr int A_TOT = RB * 16 * CIN / 4, B_TOT = CB * 16 * CIN / 4;   // float4 per operand tile
     constexpr int A_F4 = (A_TOT + T - 1) / T, B_F4 = (B_TOT + T - 1) / T;
     __shared__ int s_idx[RB][28 * 16];
     __shared__ unsigned s_mask[RB];
-    __shared__ float s_xf[2][CIN];
+    __shared__ float s_xf[2][512];                                  // folded BatchNorm affine of all input channels
     __shared__ __attribute__((aligned(16))) float s_a[2][G][RB * 16][LDA];   // G filter offsets per step
     __shared__ __attribute__((aligned(16))) float s_b[2][G][CB * 16][LDA];
     __shared__ double s_p[2][RB][CB * 16];
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         if (lane == 0) s_mask[rb] = amask;
     }
     if (xf)
-        for (int e = tid; e < CIN; e += T) { s_xf[0][e] = g.xf_scale[e]; s_xf[1][e] = g.xf_shift[e]; }
+        for (int e = tid; e < g.cin; e += T) { s_xf[0][e] = g.xf_scale[e]; s_xf[1][e] = g.xf_shift[e]; }
     __syncthreads();
     unsigned m = 0u;
 #pragma unroll
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 ra[G][A_F4], rb_[G][B_F4];
-    auto fetch = [&](int t, int gi) {
+    const int cin = g.cin, nch = cin / CIN;   // input-channel chunks per offset
+    auto fetch = [&](int t, int ch, int gi) {
         const int o = g.flip ? (K - 1 - t) : t;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
@@ -74,17 +75,20 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             if (A_TOT % T == 0 || e < A_TOT) {
                 const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
                 const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
-                ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * CIN + 4 * c4);
+                ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * cin + ch * CIN + 4 * c4);
             }
         }
-        const float *wo = g.wt + ((long)o * cout + tile_col0) * CIN;
+        const float *wo = g.wt + ((long)o * cout + tile_col0) * cin + ch * CIN;
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             const int e = j * T + tid;
-            if (B_TOT % T == 0 || e < B_TOT) rb_[gi][j] = *(const f32x4 *)(wo + 4 * (long)e);
+            if (B_TOT % T == 0 || e < B_TOT) {
+                const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
+                rb_[gi][j] = *(const f32x4 *)(wo + (long)col * cin + 4 * c4);
+            }
         }
     };
-    auto park = [&](int t, int buf, int gi) {
+    auto park = [&](int t, int ch, int buf, int gi) {
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
             const int e = j * T + tid;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
                 f32x4 v = ra[gi][j];
                 if (xf) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], s_xf[0][4 * c4 + k], s_xf[1][4 * c4 + k]), 0.f);
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], s_xf[0][ch * CIN + 4 * c4 + k], s_xf[1][ch * CIN + 4 * c4 + k]), 0.f);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = have ? v[k] : 0.f;
@@ -114,32 +118,36 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     // 2. offset loop, G active offsets per step (a step with one 16..64-channel offset is too thin to cover a
     //    memory round trip: 4*KS MFMAs per wave): the next group's loads are in flight during the MFMAs of the
     //    current one; one LDS-only barrier per step
-    int tc[G], tn[G];
-    auto take = [&](int (&ts)[G]) -> int {
+    // a step is one (offset, channel chunk) pair; nch == 1 for cin <= 128
+    int tc[G], tn[G], cc[G], cn[G];
+    int t_run = -1, c_run = 0;   // walker over (active offset, chunk)
+    auto take = [&](int (&ts)[G], int (&cs)[G]) -> int {
         int cnt = 0;
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            ts[gi] = -1;
-            if (m) { ts[gi] = __builtin_ctz(m); m &= m - 1u; ++cnt; }
+            ts[gi] = -1; cs[gi] = 0;
+            if (t_run >= 0 && c_run + 1 < nch) { ++c_run; ts[gi] = t_run; cs[gi] = c_run; ++cnt; }
+            else if (m) { t_run = __builtin_ctz(m); m &= m - 1u; c_run = 0; ts[gi] = t_run; cs[gi] = 0; ++cnt; }
+            else t_run = -1;
         }
         return cnt;
     };
     int buf = 0;
-    int n_cur = take(tc);
+    int n_cur = take(tc, cc);
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
-        if (tc[gi] >= 0) fetch(tc[gi], gi);
+        if (tc[gi] >= 0) fetch(tc[gi], cc[gi], gi);
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
-        if (tc[gi] >= 0) park(tc[gi], 0, gi);
+        if (tc[gi] >= 0) park(tc[gi], cc[gi], 0, gi);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     while (n_cur > 0) {
-        const int n_next = take(tn);
+        const int n_next = take(tn, cn);
 #pragma unroll
         for (int gi = 0; gi < G; ++gi)
-            if (tn[gi] >= 0) fetch(tn[gi], gi);
+            if (tn[gi] >= 0) fetch(tn[gi], cn[gi], gi);
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
             if (tc[gi] < 0 || !((my_mask >> tc[gi]) & 1u)) continue;  // wave-uniform
@@ -158,12 +166,12 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         }
 #pragma unroll
         for (int gi = 0; gi < G; ++gi)
-            if (tn[gi] >= 0) park(tn[gi], buf ^ 1, gi);
+            if (tn[gi] >= 0) park(tn[gi], cn[gi], buf ^ 1, gi);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int gi = 0; gi < G; ++gi) tc[gi] = tn[gi];
+        for (int gi = 0; gi < G; ++gi) { tc[gi] = tn[gi]; cc[gi] = cn[gi]; }
         n_cur = n_next;
         buf ^= 1;
     }
@@ -261,13 +269,22 @@ static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
 int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st)
 {
     const int nblk = a.cout / 16;
-    switch (ks) {
+    if (a.cin > 512) return 0;   // s_xf holds 512 channels
+    // channels per step: the whole row up to 128 channels, else the largest chunk (in 16s) that divides it
+    int kc = ks;
+    if (ks > 8) {
+        kc = 1;
+        for (int d : {8, 7, 6, 5, 4, 3, 2})
+            if (ks % d == 0) { kc = d; break; }
+    }
+    switch (kc) {
     case 1: return launch_tile_ks<1>(a, n_out, nblk, st);
     case 2: return launch_tile_ks<2>(a, n_out, nblk, st);
     case 3: return launch_tile_ks<3>(a, n_out, nblk, st);
     case 4: return launch_tile_ks<4>(a, n_out, nblk, st);
     case 5: return launch_tile_ks<5>(a, n_out, nblk, st);
     case 6: return launch_tile_ks<6>(a, n_out, nblk, st);
+    case 7: return launch_tile_ks<7>(a, n_out, nblk, st);
     case 8: return launch_tile_ks<8>(a, n_out, nblk, st);
     default: return 0;
     }
