@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, c
 {
     __shared__ int s_in[DW_LIST], s_out[DW_LIST];
     __shared__ int s_wcnt[4];
-    __shared__ float s_a[DW_KT][DW_MAXI * 16 + 16];
-    __shared__ float s_b[DW_KT][DW_MAXN * 16 + 32];
+    __shared__ __attribute__((aligned(16))) float s_a[2][DW_KT][DW_MAXI * 16 + 16];
+    __shared__ __attribute__((aligned(16))) float s_b[2][DW_KT][DW_MAXN * 16 + 32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
@@ -79,48 +79,83 @@ __global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, c
             cnt += tot;
             __syncthreads();
         }
-        // consume full batches (and the final partial one)
+        // consume full batches (and the final partial one).  Software pipeline: the rows of batch b+1 are in flight
+        // (registers) while the MFMAs of batch b run out of LDS; loads are unconditional (clamped indices) because a
+        // branch around a load makes hipcc wait for every load separately; the barrier is LDS-only (no vmcnt drain).
         int done = 0;
-        while (cnt - done >= DW_KT || (last && cnt - done > 0)) {
-            const int nb = min(DW_KT, cnt - done);
-            // stage gathered x rows and dy rows (this tile's columns), zero-fill the tail
-            for (int e = tid; e < DW_KT * (ci_w / 4); e += 256) {
-                int rr = e / (ci_w / 4), c4 = e - rr * (ci_w / 4);
-                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rr < nb) {
-                    v = *(const f32x4 *)(x + (long)s_in[done + rr] * cin + ci0 + 4 * c4);
+        const int nbatch = last ? (cnt + DW_KT - 1) / DW_KT : cnt / DW_KT;
+        const int a_tot = DW_KT * (ci_w / 4), b_tot = DW_KT * (co_w / 4);
+        f32x4 ra[2], rb[3];
+        auto prefetch = [&](int b) {
+            const int base = b * DW_KT, nb = min(DW_KT, cnt - base);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = min(j * 256 + tid, a_tot - 1);
+                const int rr = e / (ci_w / 4), c4 = e - rr * (ci_w / 4);
+                ra[j] = *(const f32x4 *)(x + (long)s_in[base + min(rr, nb - 1)] * cin + ci0 + 4 * c4);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = min(j * 256 + tid, b_tot - 1);
+                const int rr = e / (co_w / 4), c4 = e - rr * (co_w / 4);
+                rb[j] = *(const f32x4 *)(dy + (long)s_out[base + min(rr, nb - 1)] * cout + co0 + 4 * c4);
+            }
+        };
+        auto park = [&](int b, int buf) {
+            const int nb = min(DW_KT, cnt - b * DW_KT);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = j * 256 + tid;
+                if (e < a_tot) {
+                    const int rr = e / (ci_w / 4), c4 = e - rr * (ci_w / 4);
+                    f32x4 v = ra[j];
                     if (xf_scale) {  // the conv's input was relu(x*scale + shift): recompute it on the fly
                         const f32x4 sc = *(const f32x4 *)(xf_scale + ci0 + 4 * c4);
                         const f32x4 sh = *(const f32x4 *)(xf_shift + ci0 + 4 * c4);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
                     }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = rr < nb ? v[k] : 0.f;   // zero-fill the tail of a partial batch
+                    *(f32x4 *)&s_a[buf][rr][4 * c4] = v;
                 }
-                *(f32x4 *)&s_a[rr][4 * c4] = v;
             }
-            for (int e = tid; e < DW_KT * (co_w / 4); e += 256) {
-                int rr = e / (co_w / 4), c4 = e - rr * (co_w / 4);
-                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rr < nb) v = *(const f32x4 *)(dy + (long)s_out[done + rr] * cout + co0 + 4 * c4);
-                *(f32x4 *)&s_b[rr][4 * c4] = v;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = j * 256 + tid;
+                if (e < b_tot) {
+                    const int rr = e / (co_w / 4), c4 = e - rr * (co_w / 4);
+                    f32x4 v = rb[j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = rr < nb ? v[k] : 0.f;
+                    *(f32x4 *)&s_b[buf][rr][4 * c4] = v;
+                }
             }
-            __syncthreads();
+        };
+        if (nbatch > 0) prefetch(0);
+        for (int b = 0; b < nbatch; ++b) {
+            const int buf = b & 1;
+            park(b, buf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (b + 1 < nbatch) prefetch(b + 1);
 #pragma unroll
             for (int s = 0; s < DW_SLOTS; ++s) {
-                int b = wave + 4 * s;
-                if (b < nblk) {  // wave-uniform
-                    int mi = b / ni_n, ni = b - mi * ni_n;
+                int blk = wave + 4 * s;
+                if (blk < nblk) {  // wave-uniform
+                    int mi = blk / ni_n, ni = blk - mi * ni_n;
 #pragma unroll
                     for (int ks = 0; ks < DW_KT / 4; ++ks) {
-                        float av = s_a[4 * ks + q][mi * 16 + m];
-                        float bv = s_b[4 * ks + q][ni * 16 + m];
+                        float av = s_a[buf][4 * ks + q][mi * 16 + m];
+                        float bv = s_b[buf][4 * ks + q][ni * 16 + m];
                         acc[s] = MFMA16(av, bv, acc[s]);
                     }
                 }
             }
-            __syncthreads();
-            done += nb;
+            done += min(DW_KT, cnt - b * DW_KT);
         }
+        __syncthreads();
         // move the remainder (< DW_KT pairs) to the front of the list
         int rem = cnt - done;
         int vi = 0, vo = 0;
