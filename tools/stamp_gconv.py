@@ -11,18 +11,19 @@ lv, cin, cout = 3, 64, 64
 n = geo.n[lv]
 x = torch.randn(n, cin, device=dev); wt = torch.randn(27, cout, cin, device=dev) * 0.05; y = torch.empty(n, cout, device=dev)
 nwg = (n + 63) // 64
-part = torch.zeros(max(nwg * 8, L.urn_gconv_part_bytes(n, cout) // 8), dtype=torch.float64, device=dev)
+nwg = (n + 31) // 32
+dbgbuf = torch.zeros(max(nwg * 8 * 8, n * cout), dtype=torch.float32, device=dev)
 a = L_.GConvArgs(x=x.data_ptr(), wt=wt.data_ptr(), tbl=geo.nbr[lv].data_ptr(), ld=geo.ld, K=27, flip=0, n_out=n, cin=cin, cout=cout,
-                 y=y.data_ptr(), epilogue=1, part=part.data_ptr())
-L.urn_set_option(b'gconv_kernel', 4); L.urn_set_option(b'gconv_dbg', 32)
+                 y=y.data_ptr(), res=dbgbuf.data_ptr())
+L.urn_set_option(b'gconv_kernel', 6); L.urn_set_option(b'gconv_dbg', 32)
 npart = ctypes.c_int()
 for _ in range(3):
     L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a), ctypes.byref(npart), L_.stream()))
 torch.cuda.synchronize()
-p = part[:nwg * 8].view(nwg, 8).cpu().numpy()
-steps = p[:, 5].mean()
-names = ['frag reads', 'fetch issue', 'mfma issue', 'park(+vm wait)', 'barrier']
-print('workgroups %d, steps per workgroup %.1f' % (nwg, steps))
+p = dbgbuf[:nwg * 8 * 8].view(nwg * 8, 8).cpu().numpy()
+names = ['fetch issue', 'frag+mfma issue', 'park(+vm wait)', 'barrier']
+steps = np.maximum(p[:, 4], 1)
+print('tile<4,2,4>: workgroups %d (8 waves), steps per wave %.1f' % (nwg, p[:, 4].mean()))
 for i, nm in enumerate(names):
-    print('%-16s %8.0f cycles per step' % (nm, (p[:, i] / np.maximum(p[:, 5], 1)).mean()))
-print('sum %.0f cycles per step' % (p[:, :5].sum(1) / np.maximum(p[:, 5], 1)).mean())
+    print('%-18s %8.0f cycles per step (mean over waves)' % (nm, (p[:, i] / steps).mean()))
+print('sum %.0f cycles per step' % (p[:, :4].sum(1) / steps).mean())

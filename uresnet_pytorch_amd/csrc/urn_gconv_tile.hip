@@ -12,7 +12,7 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int KS, int RB, int CB, int G>
+template <int KS, int RB, int CB, int G, int STAMP = 0>
 __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 {
     constexpr int CIN = KS * 16;                                    // channels per step (a chunk of g.cin)
@@ -143,11 +143,21 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    unsigned long long st_fetch = 0, st_mfma = 0, st_park = 0, st_bar = 0, st_n = 0;   // STAMP build only
+#define URN_STAMP(v)                                                                          \
+    unsigned long long v = 0;                                                                 \
+    if (STAMP) {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    }
     while (n_cur > 0) {
+        URN_STAMP(c0)
         const int n_next = take(tn, cn);
 #pragma unroll
         for (int gi = 0; gi < G; ++gi)
             if (tn[gi] >= 0) fetch(tn[gi], cn[gi], gi);
+        URN_STAMP(c1)   // next group's global loads issued
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
             if (tc[gi] < 0 || !((my_mask >> tc[gi]) & 1u)) continue;  // wave-uniform
@@ -164,16 +174,26 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
                 }
             }
         }
+        URN_STAMP(c2)   // fragment reads + MFMAs issued
 #pragma unroll
         for (int gi = 0; gi < G; ++gi)
             if (tn[gi] >= 0) park(tn[gi], cn[gi], buf ^ 1, gi);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        URN_STAMP(c3)   // next group parked (includes the wait for its global data)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        URN_STAMP(c4)   // barrier passed
+        if (STAMP) { st_fetch += c1 - c0; st_mfma += c2 - c1; st_park += c3 - c2; st_bar += c4 - c3; st_n += 1; }
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) { tc[gi] = tn[gi]; cc[gi] = cn[gi]; }
         n_cur = n_next;
         buf ^= 1;
+    }
+#undef URN_STAMP
+    if (STAMP && lane == 0 && g.e_x == nullptr && g.res != nullptr) {
+        // diagnostic build: cycle sums of every wave go to the buffer passed as `res` (results are still written)
+        float *o = const_cast<float *>(g.res) + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * (RB * CB) + wave) * 8;
+        o[0] = (float)st_fetch; o[1] = (float)st_mfma; o[2] = (float)st_park; o[3] = (float)st_bar; o[4] = (float)st_n;
     }
 
     // 3. epilogue: one 16x16 block per wave.  C layout: col = lane&15, row = (lane>>4)*4 + reg
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             if (row >= n_out) continue;
             const long off = row * cout + col;
             float v = acc[i] + acc2[i];
-            if (g.res) v += g.res[off];
+            if (g.res && !STAMP) v += g.res[off];
             if (g.epi == 1) {
                 s0 += (double)v;
                 s1 += (double)v * (double)v;
@@ -259,6 +279,13 @@ static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
     if (g_tile_rb > 0) rb = g_tile_rb;
     if (g_tile_cb > 0 && nblk % g_tile_cb == 0) cb = g_tile_cb;
     if (!lds_ok(rb, cb)) return 0;
+    if ((a.dbg & 32) && KS == 4 && a.cout == 64) {   // diagnostic stamp build of one shape
+        if constexpr (KS == 4) {
+            const long bx = (n_out + 31) / 32;
+            hipLaunchKernelGGL((k_gconv_tile<4, 2, 4, 1, 1>), dim3((unsigned)bx, 1), dim3(512), 0, st, a);
+            return (int)bx;
+        }
+    }
 #define URN_TL(RBv, CBv) if (rb == RBv && cb == CBv) return launch_tile2<KS, RBv, CBv>(a, n_out, st);
     URN_TL(1, 1) URN_TL(2, 1) URN_TL(4, 1) URN_TL(1, 2) URN_TL(2, 2) URN_TL(4, 2) URN_TL(1, 3) URN_TL(2, 3) URN_TL(4, 3)
     URN_TL(1, 4) URN_TL(2, 4) URN_TL(4, 4) URN_TL(1, 5) URN_TL(2, 5)
