@@ -159,6 +159,23 @@ typedef struct {
         float *mean, *invstd, *scale, *shift, *running_mean, *running_var;
     } fin_bn[2];
     float *fin_dgamma, *fin_dbeta, *fin_coef0, *fin_coef1;
+    /* Accumulated statistics (2-D tile kernel only; removes the urn_bn_finalize_* launches from the chain).
+     * Producer side: part_slots > 0 makes the epilogue ADD its column sums with fp64 atomics into row
+     * (workgroup % part_slots) of `part`, a [part_slots][2][cout] slab the caller has zeroed -- the same layout
+     * as a partial slab with n_part = part_slots, so urn_bn_finalize_* still apply to it.  The order of the
+     * additions is not fixed: the fp64 sums can differ in their last bits from run to run.
+     * Consumer side: xs_sums[0] != NULL makes every workgroup derive the folded affine of its input rows from
+     * such slabs instead of reading xf_scale/xf_shift: channels [0, xs_split) from xs_sums[0] (row length
+     * xs_ld[0]), channels [xs_split, cin) from xs_sums[1] (a channel concat; xs_split = cin when there is one
+     * slab); statistics over xs_n rows, fin_eps; workgroup 0 also stores mean/invstd/scale/shift (cin each, for
+     * the backward pass) and updates the running statistics with fin_momentum when those pointers are set. */
+    int part_slots;
+    int xs_slots, xs_split;
+    int xs_ld[2];
+    const double *xs_sums[2];
+    int64_t xs_n;
+    const float *xs_gamma, *xs_beta;
+    float *xs_mean, *xs_invstd, *xs_scale, *xs_shift, *xs_running_mean, *xs_running_var;
 } urn_gconv_args;
 int64_t urn_gconv_part_bytes(int64_t n_out, int cout);
 int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);
@@ -177,6 +194,11 @@ int urn_bn_finalize_bwd(const double *part, int n_part, int64_t n, int c, float 
 int urn_bn_bwd_apply(const float *x, const float *g, const float *extra, int64_t n, int c,
                      const float *gamma, const float *mean, const float *invstd, const float *coef0,
                      const float *coef1, float *dx, void *stream);
+/* the same with the coefficients taken from an accumulated slab ([slots][2][c], see part_slots): c0 = sum g / n,
+ * c1 = sum g*xhat / n; dgamma/dbeta are ACCUMULATED into by the first workgroup.  c <= 512, c % 4 == 0. */
+int urn_bn_bwd_apply_sums(const float *x, const float *g, const float *extra, int64_t n, int c,
+                          const float *gamma, const float *mean, const float *invstd, const double *sums,
+                          int slots, float *dgamma, float *dbeta, float *dx, void *stream);
 
 /* scn.OutputLayer (reference uresnet_sparse.py:24): y[i,:] = x[idx[i],:]; and its
  * backward dx[idx[i],:] += dy[i,:] (fp32 atomics; caller zeroes dx). */
@@ -215,6 +237,8 @@ int urn_ce_bwd(const float *logits, const float *label, const float *batch_id, i
 typedef struct urn_net urn_net;
 #define URN_NET_UNFUSED 1        /* keep BatchNorm as separate passes (debug / A-B) */
 #define URN_NET_SINGLE_STREAM 2  /* do not run weight gradients on a side stream */
+#define URN_NET_SLAB_STATS 4     /* BatchNorm statistics through per-workgroup slabs + finalize launches (fixed summation
+                                    order) instead of the accumulated slabs (part_slots) */
 int urn_net_create(int m, int num_levels, int reps, int num_class, double eps, double momentum, int flags,
                    urn_net **out);
 void urn_net_destroy(urn_net *net);

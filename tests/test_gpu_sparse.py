@@ -249,7 +249,7 @@ def test_executor_matches_per_layer_path(dev):
     P = orc.init_params(m, L, nc, seed=2)
     data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
     res = {}
-    for name, use_ex, fl in (('fused', True, 0), ('unfused', True, 1), ('layers', False, 0)):
+    for name, use_ex, fl in (('fused', True, 0), ('slab', True, 4), ('unfused', True, 1), ('layers', False, 0)):
         net = make_model(flags, P, dev)
         net.use_executor = use_ex
         net.executor_flags = fl
@@ -269,6 +269,13 @@ def test_executor_matches_per_layer_path(dev):
         assert rel(res['fused'][1][k], res['layers'][1][k]) < 5e-5, k
     for k in res['layers'][2]:
         assert rel(res['fused'][2][k], res['layers'][2][k]) < 1e-6, k
+    # URN_NET_SLAB_STATS (per-workgroup slabs + finalize launches, fixed summation order) against the default
+    # accumulated statistics: same fp64 sums up to their last bits
+    assert rel(res['slab'][0], res['layers'][0]) < 1e-5 and rel(res['slab'][0], res['fused'][0]) < 2e-6
+    for k in res['layers'][1]:
+        assert rel(res['slab'][1][k], res['layers'][1][k]) < 5e-5, k
+    for k in res['layers'][2]:
+        assert rel(res['slab'][2][k], res['fused'][2][k]) < 1e-6, k
 
 
 def test_fused_conv_pieces_vs_oracle(dev):
@@ -306,7 +313,8 @@ def test_fused_conv_pieces_vs_oracle(dev):
     # weight gradient with the transform
     dy = rng.normal(size=(n, cout)).astype(np.float32)
     dW = torch.zeros_like(Wt)
-    L_.check(L.urn_gconv_bwd_dw_ex(xt.data_ptr(), sc.data_ptr(), sh.data_ptr(), t(dy).data_ptr(), geo.nbr[0].data_ptr(),
+    dyt = t(dy)
+    L_.check(L.urn_gconv_bwd_dw_ex(xt.data_ptr(), sc.data_ptr(), sh.data_ptr(), dyt.data_ptr(), geo.nbr[0].data_ptr(),
                                    geo.ld, 27, n, cin, cout, dW.data_ptr(), L_.stream()))
     du_ref, dW_ref = orc.conv_bwd(u_ref, W, ref.nbr[0], dy, ref.nbr_inv[0])
     assert rel(dW.cpu().numpy(), dW_ref) < TOL
@@ -314,7 +322,6 @@ def test_fused_conv_pieces_vs_oracle(dev):
     gbuf = torch.empty((n, cin), device=dev)
     part2 = torch.zeros(L.urn_gconv_part_bytes(n, cin) // 8, dtype=torch.float64, device=dev)
     mt, it = t(mean), t(invstd)
-    dyt = t(dy)
     a2 = A(x=dyt.data_ptr(), wt=Wt.data_ptr(), tbl=geo.nbr[0].data_ptr(), ld=geo.ld, K=27, flip=1, n_out=n, cin=cout, cout=cin,
            y=gbuf.data_ptr(), epilogue=2, part=part2.data_ptr(), e_x=xt.data_ptr(), e_scale=sc.data_ptr(),
            e_shift=sh.data_ptr(), e_mean=mt.data_ptr(), e_invstd=it.data_ptr())
@@ -323,12 +330,62 @@ def test_fused_conv_pieces_vs_oracle(dev):
     L_.check(L.urn_bn_finalize_bwd(part2.data_ptr(), npart.value, n, cin, dg.data_ptr(), db.data_ptr(), coef.data_ptr(),
                                    coef.data_ptr() + 4 * cin, L_.stream()))
     extra = rng.normal(size=(n, cin)).astype(np.float32)
+    gt, bt, et = t(g_), t(b_), t(extra)   # keep the device copies alive across the launches
     dx = torch.empty((n, cin), device=dev)
-    L_.check(L.urn_bn_bwd_apply(xt.data_ptr(), gbuf.data_ptr(), t(extra).data_ptr(), n, cin, t(g_).data_ptr(), mt.data_ptr(),
+    L_.check(L.urn_bn_bwd_apply(xt.data_ptr(), gbuf.data_ptr(), et.data_ptr(), n, cin, gt.data_ptr(), mt.data_ptr(),
                                 it.data_ptr(), coef.data_ptr(), coef.data_ptr() + 4 * cin, dx.data_ptr(), L_.stream()))
     dx_ref, dg_ref, db_ref = orc.bn_relu_bwd(x, u_ref, du_ref, g_, mean, invstd, True)
     assert rel(dx.cpu().numpy(), dx_ref + extra) < 5 * TOL
     assert rel(dg.cpu().numpy(), dg_ref) < 5 * TOL and rel(db.cpu().numpy(), db_ref) < 5 * TOL
+
+    # --- accumulated statistics (part_slots / xs_*): the same three steps without finalize launches -------------
+    SL = 8
+    # (a) producer: the column sums of x itself are produced by a 1x1 gather conv with identity weights
+    eye = t(np.eye(cin, dtype=np.float32)[None])
+    x2 = torch.empty((n, cin), device=dev)
+    sums_x = torch.zeros((SL, 2, cin), dtype=torch.float64, device=dev)
+    a3 = A(x=xt.data_ptr(), wt=eye.data_ptr(), tbl=geo.nbr[0].data_ptr() + 13 * geo.ld * 4, ld=geo.ld, K=1, flip=0, n_out=n,
+           cin=cin, cout=cin, y=x2.data_ptr(), epilogue=1, part=sums_x.data_ptr(), part_slots=SL)
+    L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a3), ctypes.byref(npart), L_.stream()))
+    assert npart.value == SL and torch.equal(x2, xt)
+    tot = sums_x.sum(0).cpu().numpy()
+    assert rel(tot[0], x.astype(np.float64).sum(0)) < 1e-12 and rel(tot[1], (x.astype(np.float64) ** 2).sum(0)) < 1e-12
+    # (b) consumer derives scale/shift from the sums (two slabs = a channel concat), stores mean/invstd/scale/shift
+    h = cin // 2
+    sa = sums_x[:, :, :h].contiguous(); sb = sums_x[:, :, h:].contiguous()
+    outs = [torch.zeros(cin, device=dev) for _ in range(4)]
+    rm, rv = torch.zeros(cin, device=dev), torch.ones(cin, device=dev)
+    y2 = torch.empty((n, cout), device=dev)
+    sums_y = torch.zeros((SL, 2, cout), dtype=torch.float64, device=dev)
+    a4 = A(x=xt.data_ptr(), wt=wt.data_ptr(), tbl=geo.nbr[0].data_ptr(), ld=geo.ld, K=27, flip=0, n_out=n, cin=cin, cout=cout,
+           y=y2.data_ptr(), epilogue=1, part=sums_y.data_ptr(), part_slots=SL, fin_eps=1e-4, fin_momentum=0.99,
+           xs_slots=SL, xs_split=h, xs_n=n, xs_gamma=gt.data_ptr(), xs_beta=bt.data_ptr(),
+           xs_mean=outs[0].data_ptr(), xs_invstd=outs[1].data_ptr(), xs_scale=outs[2].data_ptr(), xs_shift=outs[3].data_ptr(),
+           xs_running_mean=rm.data_ptr(), xs_running_var=rv.data_ptr())
+    a4.xs_ld[0], a4.xs_ld[1] = h, cin - h
+    a4.xs_sums[0], a4.xs_sums[1] = sa.data_ptr(), sb.data_ptr()
+    L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a4), ctypes.byref(npart), L_.stream()))
+    assert rel(y2.cpu().numpy(), y_ref) < TOL
+    assert rel(outs[0].cpu().numpy(), mean) < 1e-6 and rel(outs[1].cpu().numpy(), invstd) < 1e-6
+    assert rel(outs[2].cpu().numpy(), scale) < 1e-6 and rel(outs[3].cpu().numpy(), shift) < 1e-5
+    var = x.astype(np.float64).var(0)
+    assert rel(rm.cpu().numpy(), 0.01 * mean) < 1e-5 and rel(rv.cpu().numpy(), 0.99 + 0.01 * var) < 1e-6
+    ty = sums_y.sum(0).cpu().numpy()
+    assert rel(ty[0], y_ref.astype(np.float64).sum(0)) < 1e-6
+    # (c) backward reduce accumulated, apply straight from the slab
+    g2 = torch.empty((n, cin), device=dev)
+    sums_g = torch.zeros((SL, 2, cin), dtype=torch.float64, device=dev)
+    a5 = A(x=dyt.data_ptr(), wt=Wt.data_ptr(), tbl=geo.nbr[0].data_ptr(), ld=geo.ld, K=27, flip=1, n_out=n, cin=cout, cout=cin,
+           y=g2.data_ptr(), epilogue=2, part=sums_g.data_ptr(), part_slots=SL, e_x=xt.data_ptr(), e_scale=sc.data_ptr(),
+           e_shift=sh.data_ptr(), e_mean=mt.data_ptr(), e_invstd=it.data_ptr())
+    L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a5), ctypes.byref(npart), L_.stream()))
+    assert torch.equal(g2, gbuf)
+    dg2 = torch.zeros(cin, device=dev); db2 = torch.zeros(cin, device=dev); dx2 = torch.empty((n, cin), device=dev)
+    L_.check(L.urn_bn_bwd_apply_sums(xt.data_ptr(), g2.data_ptr(), et.data_ptr(), n, cin, gt.data_ptr(), mt.data_ptr(),
+                                     it.data_ptr(), sums_g.data_ptr(), SL, dg2.data_ptr(), db2.data_ptr(), dx2.data_ptr(),
+                                     L_.stream()))
+    assert rel(dx2.cpu().numpy(), dx_ref + extra) < 5 * TOL and rel(dx2.cpu().numpy(), dx.cpu().numpy()) < 1e-6
+    assert rel(dg2.cpu().numpy(), dg_ref) < 5 * TOL and rel(db2.cpu().numpy(), db_ref) < 5 * TOL
 
 
 def test_executor_two_forwards_before_backward(dev):

@@ -17,7 +17,7 @@ crit = SparseSegmentationLoss(flags)
 variants = {}
 from uresnet_pytorch_amd import lib as _lib
 L = _lib.load()
-for name, fl in (('fused+side', 0), ('unfused+side', 1)):
+for name, fl in (('fused, accumulated stats', 0), ('fused, slab stats', 4), ('unfused', 1)):
     torch.manual_seed(0)
     net = SparseUResNet(flags).to(dev).train(); net.executor_flags = fl
     g = parallel.FlatGradients(net); opt = torch.optim.Adam(net.parameters(), lr=1e-3)
@@ -27,7 +27,7 @@ for name, fl in (('fused+side', 0), ('unfused+side', 1)):
 for s in variants.values():
     for _ in range(5): s()
 res = {k: [] for k in variants}
-kernels = {'tile2d(6)': 6, 'lds64x16(4)': 4, 'reg(3)': 3}
+kernels = {'tile2d(6)': 6}
 res = {(k, kn): [] for k in variants for kn in kernels}
 for rnd in range(4):
     for kn, kv in kernels.items():

@@ -467,3 +467,60 @@ extern "C" int urn_bn_bwd_apply(const float *x, const float *g, const float *ext
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
+
+// bn_bwd_apply with the two coefficients taken from an accumulated slab ([slots][2][c], gather-conv epilogue 2 with
+// part_slots): every block first reduces the slots into LDS, then streams its share of the elements.  Block 0
+// accumulates dgamma/dbeta.  EPB elements per block so that the slab re-read stays small beside the stream.
+#define URN_APPLY_EPB 4096
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restrict__ x, const float *__restrict__ g,
+                                                           const float *__restrict__ extra, long total, int c,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           const double *__restrict__ sums, int slots, double inv_n,
+                                                           float *dgamma, float *dbeta, float *__restrict__ dx)
+{
+    __shared__ float s_c0[512], s_c1[512], s_a[512], s_mu[512], s_is[512];
+    for (int e = threadIdx.x; e < c; e += 256) {
+        double v0 = 0.0, v1 = 0.0;
+        for (int k = 0; k < slots; ++k) { v0 += sums[(long)(2 * k) * c + e]; v1 += sums[(long)(2 * k + 1) * c + e]; }
+        s_c0[e] = (float)(v0 * inv_n);
+        s_c1[e] = (float)(v1 * inv_n);
+        const float is = invstd[e];
+        s_is[e] = is; s_mu[e] = mean[e]; s_a[e] = gamma[e] * is;
+        if (blockIdx.x == 0) { dbeta[e] += (float)v0; dgamma[e] += (float)v1; }
+    }
+    __syncthreads();
+    const long base = (long)blockIdx.x * URN_APPLY_EPB;
+#pragma unroll
+    for (int it = 0; it < URN_APPLY_EPB / 1024; ++it) {
+        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+        if (i >= total) break;   // c % 4 == 0
+        const int col = (int)(i % c);
+        const f32x4 xv = *(const f32x4 *)(x + i), gv = *(const f32x4 *)(g + i);
+        f32x4 ev = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (extra) ev = *(const f32x4 *)(extra + i);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - s_mu[col + k]) * s_is[col + k];
+            o[k] = s_a[col + k] * (gv[k] - s_c0[col + k] - xh * s_c1[col + k]) + ev[k];
+        }
+        *(f32x4 *)(dx + i) = o;
+    }
+}
+
+extern "C" int urn_bn_bwd_apply_sums(const float *x, const float *g, const float *extra, int64_t n, int c,
+                                     const float *gamma, const float *mean, const float *invstd, const double *sums,
+                                     int slots, float *dgamma, float *dbeta, float *dx, void *stream)
+{
+    URN_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 512 && n >= 0 && gamma && mean && invstd && sums && slots > 0 && dgamma && dbeta,
+                  "bad argument (c must be a multiple of 4, at most 512)");
+    const long total = (long)n * c;
+    if (total == 0) return URN_OK;
+    URN_CHECK_ARG(x && g && dx, "null pointer");
+    hipLaunchKernelGGL(k_bn_bwd_apply_sums, dim3(urn_cdiv(total, URN_APPLY_EPB)), dim3(256), 0, (hipStream_t)stream, x, g, extra,
+                       total, c, gamma, mean, invstd, sums, slots, 1.0 / (double)n, dgamma, dbeta, dx);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}

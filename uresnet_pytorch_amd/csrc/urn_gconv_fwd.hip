@@ -380,17 +380,37 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
         }
         a.fin_dgamma = u->fin_dgamma; a.fin_dbeta = u->fin_dbeta; a.fin_coef0 = u->fin_coef0; a.fin_coef1 = u->fin_coef1;
     }
+    // accumulated statistics: only the 2-D tile kernel implements them
+    const bool sums_mode = u->part_slots > 0 || u->xs_sums[0] != nullptr;
+    if (sums_mode) {
+        URN_CHECK_ARG(u->part_slots >= 0 && (u->part_slots == 0 || u->epilogue != 0), "part_slots without an epilogue");
+        if (u->xs_sums[0]) {
+            URN_CHECK_ARG(u->xs_slots > 0 && u->xs_split > 0 && u->xs_split <= u->cin && u->xs_gamma && u->xs_beta && u->xs_mean &&
+                          u->xs_invstd && u->xs_scale && u->xs_shift && (u->xs_split == u->cin || u->xs_sums[1]), "incomplete xs_* fields");
+        }
+        a.part_slots = u->part_slots; a.xs_slots = u->xs_slots; a.xs_split = u->xs_split;
+        a.xs_ld[0] = u->xs_ld[0]; a.xs_ld[1] = u->xs_ld[1]; a.xs_sums[0] = u->xs_sums[0]; a.xs_sums[1] = u->xs_sums[1];
+        a.xs_n = (long)u->xs_n; a.xs_gamma = u->xs_gamma; a.xs_beta = u->xs_beta; a.xs_mean = u->xs_mean; a.xs_invstd = u->xs_invstd;
+        a.xs_scale = u->xs_scale; a.xs_shift = u->xs_shift; a.xs_rm = u->xs_running_mean; a.xs_rv = u->xs_running_var;
+        a.fin_eps = u->fin_eps; a.fin_momentum = u->fin_momentum;
+    }
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_GCONV, st);
     bool ok = false;
-    if (g_opt_kernel == 6 && !in_kernel) {
+    if ((g_opt_kernel == 6 && !in_kernel) || sums_mode) {
         const int np6 = urn_gconv_tile_launch(a, ks, u->n_out, st);
         if (np6 > 0) {
             if (prof) urn_prof_end(st);
-            if (n_tiles) *n_tiles = np6;
+            const int np = u->part_slots > 0 ? u->part_slots : np6;
+            if (n_tiles) *n_tiles = np;
             URN_LAUNCH_CHECK();
-            if (want_fin) return finalize_launches(u, np6, stream);
+            if (want_fin) return finalize_launches(u, np, stream);
             return URN_OK;
+        }
+        if (sums_mode) {
+            if (prof) urn_prof_end(st);
+            urn_set_error("urn_gconv_fwd_ex: accumulated statistics need the 2-D tile kernel (cin=%d cout=%d has none)", u->cin, u->cout);
+            return URN_EUNSUPPORTED;
         }
     }
     if ((g_opt_kernel == 5 && urn_gconv_dma_launch(a, ks, u->n_out, st)) ||

@@ -26,6 +26,13 @@ struct GArgs {
         float *mean, *invstd, *scale, *shift, *running_mean, *running_var;
     } fin_bn[2];
     float *fin_dgamma, *fin_dbeta, *fin_coef0, *fin_coef1;
+    // accumulated statistics (see urn_gconv_args)
+    int part_slots, xs_slots, xs_split;
+    int xs_ld[2];
+    const double *xs_sums[2];
+    long xs_n;
+    const float *xs_gamma, *xs_beta;
+    float *xs_mean, *xs_invstd, *xs_scale, *xs_shift, *xs_rm, *xs_rv;
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };
 

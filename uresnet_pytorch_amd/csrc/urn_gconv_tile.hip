@@ -36,7 +36,8 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     const int col_base = (blockIdx.y * CB + cb) * 16;
     const int tile_col0 = blockIdx.y * CB * 16;
     const int K = g.K, cout = g.cout;
-    const bool xf = g.xf_scale != nullptr;
+    const bool xs = g.xs_sums[0] != nullptr;                        // folded affine derived here from accumulated sums
+    const bool xf = g.xf_scale != nullptr || xs;
 
     // 1. table fetch (the cb == 0 wave of every row block), masks
     if (cb == 0) {
@@ -55,8 +56,34 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         }
         if (lane == 0) s_mask[rb] = amask;
     }
-    if (xf)
+    if (xs) {
+        // BatchNorm statistics of the input rows: the producers accumulated (sum, sum of squares) into xs_slots rows;
+        // same arithmetic as k_bn_finalize_fwd_f.  Workgroup 0 keeps the results for the backward pass.
+        const bool keep = blockIdx.x == 0 && blockIdx.y == 0;
+        const double dn = (double)g.xs_n;
+        for (int e = tid; e < g.cin; e += T) {
+            const int sl = e >= g.xs_split ? 1 : 0;
+            const int ch = sl ? e - g.xs_split : e;
+            const double *p = g.xs_sums[sl] + ch;
+            const int ld = g.xs_ld[sl];
+            double v0 = 0.0, v1 = 0.0;
+            for (int k = 0; k < g.xs_slots; ++k) { v0 += p[(long)(2 * k) * ld]; v1 += p[(long)(2 * k + 1) * ld]; }
+            const double mu = g.xs_n > 0 ? v0 / dn : 0.0;
+            double var = g.xs_n > 0 ? v1 / dn - mu * mu : 0.0;
+            if (var < 0.0) var = 0.0;
+            const double is = 1.0 / sqrt(var + g.fin_eps);
+            const float sc = g.xs_gamma[e] * (float)is;
+            const float sh = fmaf(-(float)mu, sc, g.xs_beta[e]);
+            s_xf[0][e] = sc; s_xf[1][e] = sh;
+            if (keep) {
+                g.xs_mean[e] = (float)mu; g.xs_invstd[e] = (float)is; g.xs_scale[e] = sc; g.xs_shift[e] = sh;
+                if (g.xs_rm) g.xs_rm[e] = (float)(g.fin_momentum * g.xs_rm[e] + (1.0 - g.fin_momentum) * mu);
+                if (g.xs_rv) g.xs_rv[e] = (float)(g.fin_momentum * g.xs_rv[e] + (1.0 - g.fin_momentum) * var);
+            }
+        }
+    } else if (xf) {
         for (int e = tid; e < g.cin; e += T) { s_xf[0][e] = g.xf_scale[e]; s_xf[1][e] = g.xf_shift[e]; }
+    }
     __syncthreads();
     unsigned m = 0u;
 #pragma unroll
@@ -231,8 +258,14 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         double v0 = 0.0, v1 = 0.0;
 #pragma unroll
         for (int i = 0; i < RB; ++i) { v0 += s_p[0][i][tid]; v1 += s_p[1][i][tid]; }
-        g.part[((long)blockIdx.x * 2 + 0) * cout + tile_col0 + tid] = v0;
-        g.part[((long)blockIdx.x * 2 + 1) * cout + tile_col0 + tid] = v1;
+        if (g.part_slots > 0) {   // accumulate: hardware fp64 add at the L2, no return value
+            const long slot = blockIdx.x % (unsigned)g.part_slots;
+            unsafeAtomicAdd(&g.part[(slot * 2 + 0) * cout + tile_col0 + tid], v0);
+            unsafeAtomicAdd(&g.part[(slot * 2 + 1) * cout + tile_col0 + tid], v1);
+        } else {
+            g.part[((long)blockIdx.x * 2 + 0) * cout + tile_col0 + tid] = v0;
+            g.part[((long)blockIdx.x * 2 + 1) * cout + tile_col0 + tid] = v1;
+        }
     }
     (void)tile_row0;
 }

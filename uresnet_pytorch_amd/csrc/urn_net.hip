@@ -274,6 +274,30 @@ struct urn_net {
     // [coff, coff + cout) of the BatchNorm when the consumer is the second half of a channel concat)
     unsigned long fwd_stamp = 0;
     uint32_t *sync_word = nullptr;
+    // accumulated statistics (default): conv epilogues add their column sums into [SUM_SLOTS][2][c] slabs carved
+    // from one zeroed region per pass; the consuming kernels derive the BatchNorm coefficients themselves, so the
+    // chain conv -> finalize -> conv loses its middle launch (94 launches per cfg3 step)
+    static constexpr int SUM_SLOTS = 8;
+    int slab_stats = 0;                  // URN_NET_SLAB_STATS: per-workgroup slabs + finalize launches instead
+    double *sums_base = nullptr;
+    size_t sums_cap = 0, sums_off = 0;   // in doubles
+    int64_t sum_channels = 0;            // sum over convs of max(cin, cout): bounds either pass
+    bool sums_mode() const { return fused && !slab_stats; }
+    void sums_begin()
+    {
+        sums_cap = (size_t)sum_channels * SUM_SLOTS * 2;
+        sums_base = (double *)arena.alloc_bytes(sums_cap * 8);
+        sums_off = 0;
+        if (live()) check(hipMemsetAsync(sums_base, 0, sums_cap * 8, st) == hipSuccess ? URN_OK : URN_EHIP);
+    }
+    double *sums_alloc(int c)
+    {
+        const size_t need = (size_t)SUM_SLOTS * 2 * c;
+        if (sums_off + need > sums_cap) { if (!arena.dry) { urn_set_error("urn_net: statistics region exhausted"); check(URN_EINVAL); } return nullptr; }
+        double *p = arena.dry ? (double *)(uintptr_t)256 : sums_base + sums_off;
+        sums_off += need;
+        return p;
+    }
 
     void alloc_bn(BNP &b)
     {
@@ -281,7 +305,7 @@ struct urn_net {
         b.stamp = fwd_stamp;
         b.mean = arena.f32(b.c); b.invstd = arena.f32(b.c); b.scale = arena.f32(b.c); b.shift = arena.f32(b.c);
     }
-    Act conv_f(ConvP &c, const Act &in, const BNP *xf, const int32_t *tbl, int64_t n_out, const float *res, Cons c0,
+    Act conv_f(ConvP &c, const Act &in, BNP *xf, const int32_t *tbl, int64_t n_out, const float *res, Cons c0,
                Cons c1 = Cons())
     {
         c.x = in.x;
@@ -290,22 +314,44 @@ struct urn_net {
         y.x = arena.f32(n_out * c.cout);
         const bool mfma = (c.cin % 16 == 0) && (c.cout % 16 == 0);
         const bool stats = c0.bn != nullptr;
+        const bool acc = sums_mode() && mfma;         // accumulated statistics on the producing side
+        const bool xs = xf && in.st.part != nullptr;  // ... and on the consuming side (the input carries its sums)
         double *part = nullptr;
         if (stats) {
-            part = (double *)arena.alloc_bytes(mfma ? (size_t)urn_gconv_part_bytes(n_out, c.cout)
-                                                    : (size_t)urn_bn_scratch_bytes(c.cout));
-            alloc_bn(*c0.bn);
-            if (c1.bn) alloc_bn(*c1.bn);
+            if (acc) {
+                part = sums_alloc(c.cout);
+                y.st.part = part; y.st.n_part = SUM_SLOTS; y.st.ld = c.cout;
+            } else {
+                part = (double *)arena.alloc_bytes(mfma ? (size_t)urn_gconv_part_bytes(n_out, c.cout)
+                                                        : (size_t)urn_bn_scratch_bytes(c.cout));
+                alloc_bn(*c0.bn);
+                if (c1.bn) alloc_bn(*c1.bn);
+            }
         }
+        if (xs) alloc_bn(*xf);
         if (!live()) return y;
         urn_gconv_args a;
         memset(&a, 0, sizeof(a));
         a.x = in.x; a.wt = wt_all + c.w; a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
         a.cin = c.cin; a.cout = c.cout; a.res = res; a.y = y.x;
-        if (xf) { a.xf_scale = xf->scale; a.xf_shift = xf->shift; }
+        a.fin_eps = eps; a.fin_momentum = momentum;
+        if (xs) {
+            a.xs_slots = SUM_SLOTS; a.xs_n = in.n;
+            a.xs_sums[0] = in.st.part; a.xs_ld[0] = in.st.ld;
+            a.xs_split = in.st2.part ? in.c0 : c.cin;
+            if (in.st2.part) { a.xs_sums[1] = in.st2.part; a.xs_ld[1] = in.st2.ld; }
+            a.xs_gamma = params + xf->w; a.xs_beta = params + xf->b;
+            a.xs_mean = xf->mean; a.xs_invstd = xf->invstd; a.xs_scale = xf->scale; a.xs_shift = xf->shift;
+            a.xs_running_mean = running ? running + xf->run : nullptr;
+            a.xs_running_var = running ? running + xf->run + xf->c : nullptr;
+        } else if (xf) {
+            a.xf_scale = xf->scale; a.xf_shift = xf->shift;
+        }
         const Cons cons[2] = {c0, c1};
-        if (stats && mfma) {
-            a.epilogue = 1; a.part = part; a.sync_word = sync_word; a.fin_n = n_out; a.fin_eps = eps; a.fin_momentum = momentum;
+        if (stats && acc) {
+            a.epilogue = 1; a.part = part; a.part_slots = SUM_SLOTS;
+        } else if (stats && mfma) {
+            a.epilogue = 1; a.part = part; a.sync_word = sync_word; a.fin_n = n_out;
             for (int i = 0; i < 2; ++i) {
                 if (!cons[i].bn) continue;
                 BNP &b = *cons[i].bn;
@@ -350,8 +396,9 @@ struct urn_net {
                         int64_t n_out, int64_t n_in, const float *extra)
     {
         float *g = arena.f32(n_in * c.cin);
-        double *part = (double *)arena.alloc_bytes((size_t)urn_gconv_part_bytes(n_in, c.cin));
-        float *coef = arena.f32(2 * (int64_t)c.cin);
+        const bool acc = sums_mode();
+        double *part = acc ? sums_alloc(c.cin) : (double *)arena.alloc_bytes((size_t)urn_gconv_part_bytes(n_in, c.cin));
+        float *coef = acc ? nullptr : arena.f32(2 * (int64_t)c.cin);
         float *dx = arena.f32(n_in * c.cin);
         if (live()) {
             dw_launch(c, &b, dy, tbl_f, n_out);
@@ -361,11 +408,18 @@ struct urn_net {
             a.cin = c.cout; a.cout = c.cin; a.y = g;
             a.epilogue = 2; a.part = part;
             a.e_x = b.x; a.e_scale = b.scale; a.e_shift = b.shift; a.e_mean = b.mean; a.e_invstd = b.invstd;
-            a.sync_word = sync_word; a.fin_n = n_in;
-            a.fin_dgamma = grads + b.w; a.fin_dbeta = grads + b.b; a.fin_coef0 = coef; a.fin_coef1 = coef + c.cin;
             int n_part = 0;
-            check(urn_gconv_fwd_ex(&a, &n_part, st));
-            check(urn_bn_bwd_apply(b.x, g, extra, n_in, c.cin, params + b.w, b.mean, b.invstd, coef, coef + c.cin, dx, st));
+            if (acc) {
+                a.part_slots = SUM_SLOTS;
+                check(urn_gconv_fwd_ex(&a, &n_part, st));
+                check(urn_bn_bwd_apply_sums(b.x, g, extra, n_in, c.cin, params + b.w, b.mean, b.invstd, part, SUM_SLOTS,
+                                            grads + b.w, grads + b.b, dx, st));
+            } else {
+                a.sync_word = sync_word; a.fin_n = n_in;
+                a.fin_dgamma = grads + b.w; a.fin_dbeta = grads + b.b; a.fin_coef0 = coef; a.fin_coef1 = coef + c.cin;
+                check(urn_gconv_fwd_ex(&a, &n_part, st));
+                check(urn_bn_bwd_apply(b.x, g, extra, n_in, c.cin, params + b.w, b.mean, b.invstd, coef, coef + c.cin, dx, st));
+            }
         }
         return dx;
     }
@@ -406,6 +460,7 @@ struct urn_net {
             Act z = conv_f(lv.up, t, &lv.bn_u, geo.up[l], n, nullptr, c_cat);
             Act cat;
             cat.n = n; cat.c = 2 * P;
+            cat.st = x.st; cat.st2 = z.st; cat.c0 = P;   // statistics of the two halves come from their producers
             cat.x = arena.f32(n * 2 * P);
             if (live()) {
                 check(hipMemcpy2DAsync(cat.x, 2 * P * 4, x.x, P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
@@ -476,6 +531,7 @@ extern "C" int urn_net_create(int m, int num_levels, int reps, int num_class, do
     URN_CHECK_ARG(out && m > 0 && m % 16 == 0 && num_levels >= 1 && reps >= 1 && num_class > 0, "bad configuration (m must be a multiple of 16)");
     urn_net *n = new urn_net();
     n->fused = (flags & URN_NET_UNFUSED) ? 0 : 1;
+    n->slab_stats = (flags & URN_NET_SLAB_STATS) ? 1 : 0;
     n->m = m; n->L = num_levels; n->reps = reps; n->nc = num_class; n->eps = eps; n->momentum = momentum;
     for (int i = 1; i <= num_levels; ++i) n->planes.push_back(i * m);
     n->stem = n->make_conv(27, 1, m);
@@ -539,7 +595,11 @@ static void collect_convs(urn_net *net, ULevel &lv)
 
 static void transpose_all(urn_net *net)
 {
-    if (net->convs.empty()) { net->convs.push_back(&net->stem); collect_convs(net, net->u); }
+    if (net->convs.empty()) {
+        net->convs.push_back(&net->stem); collect_convs(net, net->u);
+        net->sum_channels = 0;
+        for (const ConvP *c : net->convs) net->sum_channels += std::max(c->cin, c->cout);
+    }
     net->wt_all = net->arena.f32(net->n_params);
     if (!net->live()) return;
     for (size_t base = 0; base < net->convs.size(); base += URN_MAX_CONVS) {
@@ -588,6 +648,7 @@ static void run_forward(urn_net *net, const float *site_feats)
         net->fwd_stamp++;
         net->sync_word = (uint32_t *)net->arena.alloc_bytes(256);
         if (net->live()) net->check(hipMemsetAsync(net->sync_word, 0, 256, net->st) == hipSuccess ? URN_OK : URN_EHIP);
+        if (net->sums_mode()) net->sums_begin();
         Act f;
         f.x = const_cast<float *>(site_feats); f.n = n0; f.c = 1;
         Cons c_first; c_first.bn = &net->u.pre[0].bn1;
@@ -598,6 +659,13 @@ static void run_forward(urn_net *net, const float *site_feats)
         // the last BatchNormReLU feeds the OutputLayer, not a conv: materialise it
         BNP &b = net->bn_out;
         b.x = x.x;
+        if (x.st.part) {   // accumulated statistics: the slab is a partial slab of SUM_SLOTS rows
+            net->alloc_bn(b);
+            if (net->live())
+                net->check(urn_bn_finalize_fwd(x.st.part, x.st.n_part, n0, b.c, x.st.ld, net->eps, net->params + b.w, net->params + b.b,
+                                               b.mean, b.invstd, b.scale, b.shift, net->running ? net->running + b.run : nullptr,
+                                               net->running ? net->running + b.run + b.c : nullptr, net->momentum, net->st));
+        }
         float *y = net->arena.f32(n0 * b.c);
         b.y = y;
         if (net->live())
@@ -620,6 +688,7 @@ static void run_backward(urn_net *net, const float *d_rows)
         net->check(urn_rows_scatter_add(d_rows, net->geo.row2site, net->geo.n_rows, net->m, d, net->st));
     }
     d = net->bn_bwd(net->bn_out, d, n0);
+    if (net->sums_mode()) net->sums_begin();
     d = net->fused ? net->u_b(net->u, d, 0) : net->u_bwd(net->u, d, 0);
     net->conv_bwd(net->stem, d, net->geo.nbr[0], net->geo.nbr[0], 1, n0, n0, false);
     // join: the caller's stream continues only after every weight gradient has landed

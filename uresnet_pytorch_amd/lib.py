@@ -29,7 +29,12 @@ class GConvArgs(ctypes.Structure):
                 ('e_shift', ctypes.c_void_p), ('e_mean', ctypes.c_void_p), ('e_invstd', ctypes.c_void_p),
                 ('sync_word', ctypes.c_void_p), ('fin_n', ctypes.c_int64), ('fin_eps', ctypes.c_double),
                 ('fin_momentum', ctypes.c_double), ('fin_bn', _FinBN * 2), ('fin_dgamma', ctypes.c_void_p),
-                ('fin_dbeta', ctypes.c_void_p), ('fin_coef0', ctypes.c_void_p), ('fin_coef1', ctypes.c_void_p)]
+                ('fin_dbeta', ctypes.c_void_p), ('fin_coef0', ctypes.c_void_p), ('fin_coef1', ctypes.c_void_p),
+                ('part_slots', ctypes.c_int), ('xs_slots', ctypes.c_int), ('xs_split', ctypes.c_int),
+                ('xs_ld', ctypes.c_int * 2), ('xs_sums', ctypes.c_void_p * 2), ('xs_n', ctypes.c_int64),
+                ('xs_gamma', ctypes.c_void_p), ('xs_beta', ctypes.c_void_p), ('xs_mean', ctypes.c_void_p),
+                ('xs_invstd', ctypes.c_void_p), ('xs_scale', ctypes.c_void_p), ('xs_shift', ctypes.c_void_p),
+                ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/uresnet_hip.h
@@ -72,6 +77,8 @@ SIGNATURES = {
     'urn_bn_finalize_bwd': (c_int, [c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_bn_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
+    'urn_bn_bwd_apply_sums': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'urn_rows_scatter_add': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'urn_head_fwd': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
