@@ -107,7 +107,7 @@ def main():
     data = torch.from_numpy(blob['data']).to(dev)
     label = torch.from_numpy(blob['label']).to(dev)
     grads = parallel.FlatGradients(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # one multi-tensor kernel per step
+    opt = parallel.FlatAdam(grads, lr=1e-3)   # torch.optim.Adam semantics, one pass over the flat buffers
     voxels_per_rank = int(data.shape[0])
 
     def step():

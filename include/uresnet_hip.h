@@ -225,6 +225,12 @@ int urn_ce_bwd(const float *logits, const float *label, const float *batch_id, i
                const float *weight, const float *row_lse, const double *ev, const float *grad_out, int64_t n,
                int nc, float *dlogits, void *stream);
 
+/* torch.optim.Adam (reference uresnet/trainval.py:37) over one contiguous fp32 segment: p, g, exp_avg m and
+ * exp_avg_sq v of n elements each; `step` is the 1-based step count AFTER the increment (bias corrections
+ * 1 - beta^step are formed on the host in double).  weight_decay is the L2 form (added to the gradient). */
+int urn_adam_flat(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int64_t step, void *stream);
+
 /* ------------------------------------------------------------------ whole-network executor
  * The trunk of the sparse model -- everything between scn.InputLayer and torch.nn.Linear at
  * reference uresnet_sparse.py:19-25 -- run from C++: the same kernels as the per-layer entry

@@ -492,3 +492,34 @@ def test_empty_and_tiny_inputs(dev):
     out.sum().backward()
     assert out.shape == (4, 5) and torch.isfinite(out).all()
     assert torch.allclose(out[0], out[3])               # the same site feeds every duplicate row
+
+
+def test_flat_adam_matches_torch_adam(dev):
+    """parallel.FlatAdam (urn_adam_flat over contiguous segments) against torch.optim.Adam, incl. the optimizer
+    state_dict round trip of the reference's checkpoint format (trainval.py:32-40,171-196)."""
+    from uresnet_pytorch_amd import parallel
+    torch.manual_seed(3)
+    def make():
+        torch.manual_seed(4)
+        return torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).to(dev)
+    a, b = make(), make()
+    fg = parallel.FlatGradients(a)
+    oa = parallel.FlatAdam(fg, lr=3e-3)
+    ob = torch.optim.Adam(b.parameters(), lr=3e-3)
+    x = torch.randn(64, 37, device=dev)
+    for it in range(4):
+        fg.zero(); ob.zero_grad()
+        a(x).square().sum().backward(); b(x).square().sum().backward()
+        oa.step(); ob.step()
+        if it == 1:   # checkpoint round trip through torch.optim.Adam's state layout
+            sd = oa.state_dict()
+            assert set(sd['state'][0].keys()) == {'step', 'exp_avg', 'exp_avg_sq'}
+            oa2 = parallel.FlatAdam(fg, lr=3e-3)
+            oa2.load_state_dict(sd)
+            oa = oa2
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert rel(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 2e-6
+    sa, sb = oa.state_dict(), ob.state_dict()
+    for k in sb['state']:
+        assert rel(sa['state'][k]['exp_avg_sq'].cpu().numpy(), sb['state'][k]['exp_avg_sq'].cpu().numpy()) < 1e-6
+        assert float(sa['state'][k]['step']) == float(sb['state'][k]['step'])

@@ -20,15 +20,35 @@ def run(level, cin, cout, reps=30):
     for _ in range(reps): call()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
+def run_dw(level, cin, cout, reps=30):
+    n = geo.n[level]
+    x = torch.randn(n, cin, device=dev); dy = torch.randn(n, cout, device=dev); dw = torch.zeros(27, cin, cout, device=dev)
+    def call():
+        L_.check(L.urn_gconv_bwd_dw(x.data_ptr(), dy.data_ptr(), geo.nbr[level].data_ptr(), geo.ld, 27, n, cin, cout, dw.data_ptr(), L_.stream()))
+    for _ in range(3): call()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): call()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
 shapes = [(0, 16, 16), (1, 32, 32), (2, 48, 48), (3, 64, 64), (4, 80, 80), (3, 128, 64), (2, 96, 48), (1, 64, 32), (0, 32, 16), (1, 16, 32), (2, 32, 48), (3, 48, 64), (4, 64, 80)]
-variants = [('auto', (0, 0))]
+variants = [('auto', (0, 0, 0))]
+if len(sys.argv) > 1 and sys.argv[1] == 'depth':
+    variants = [('d%d' % d, (0, 0, 0, d)) for d in (1, 2, 4)]
+if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
+    shapes = [(3, 128, 64), (2, 96, 48), (1, 64, 32), (0, 32, 16), (3, 64, 128), (2, 48, 96), (1, 32, 64), (0, 16, 32), (3, 64, 64), (4, 160, 80)]
+    variants = [('auto', (0, 0, 0))] + [('%dx%d/k%d' % (r, c, k), (r, c, k)) for k in (2, 3, 4, 8) for r in (1, 2, 4) for c in (1, 2, 3, 4)]
 for lv, ci, co in shapes:
     out = []
     for name, mw in variants:
-        L.urn_set_option(b'gconv_kernel', 6); L.urn_set_option(b'tile_rb', mw[0]); L.urn_set_option(b'tile_cb', mw[1])
-        if mw[1] and (co // 16) % mw[1]:
+        L.urn_set_option(b'gconv_kernel', 6); L.urn_set_option(b'tile_rb', mw[0]); L.urn_set_option(b'tile_cb', mw[1]); L.urn_set_option(b'tile_kc', mw[2])
+        L.urn_set_option(b'tile_depth', mw[3] if len(mw) > 3 else 0)
+        if (mw[1] and (co // 16) % mw[1]) or (mw[2] and ((ci // 16) % mw[2] or mw[0] * mw[1] > 12 or (mw[0] + mw[1]) * 128 * (mw[2] * 16 + 4) > 98304)):
             continue
         t = min(run(lv, ci, co) for _ in range(3))
         out.append('%s %.0f' % (name, t))
     fl = 2.0 * geo.rules[lv] * ci * co
-    print('L%d %3d->%3d n=%6d %s' % (lv, ci, co, geo.n[lv], ' | '.join(out)))
+    tdw = min(run_dw(lv, ci, co) for _ in range(3))
+    L.urn_set_option(b'tile_rb', 0); L.urn_set_option(b'tile_cb', 0); L.urn_set_option(b'tile_kc', 0)
+    print('L%d %3d->%3d n=%6d fwd %s us | dW %.0f us (%.1f TF)' % (lv, ci, co, geo.n[lv], ' | '.join(out), tdw, fl / tdw / 1e6))

@@ -471,7 +471,7 @@ extern "C" int urn_bn_bwd_apply(const float *x, const float *g, const float *ext
 // bn_bwd_apply with the two coefficients taken from an accumulated slab ([slots][2][c], gather-conv epilogue 2 with
 // part_slots): every block first reduces the slots into LDS, then streams its share of the elements.  Block 0
 // accumulates dgamma/dbeta.  EPB elements per block so that the slab re-read stays small beside the stream.
-#define URN_APPLY_EPB 4096
+#define URN_APPLY_EPB 2048
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restrict__ x, const float *__restrict__ g,
                                                            const float *__restrict__ extra, long total, int c,
                                                            const float *__restrict__ gamma,
@@ -481,6 +481,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restri
                                                            float *dgamma, float *dbeta, float *__restrict__ dx)
 {
     __shared__ float s_c0[512], s_c1[512], s_a[512], s_mu[512], s_is[512];
+    constexpr int IT = URN_APPLY_EPB / 1024;
+    // the element stream is issued first: it is in flight while the slab is reduced
+    const long base = (long)blockIdx.x * URN_APPLY_EPB;
+    f32x4 xv[IT], gv[IT], ev[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+        xv[it] = gv[it] = ev[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < total) {   // c % 4 == 0: a vector never straddles rows
+            xv[it] = *(const f32x4 *)(x + i); gv[it] = *(const f32x4 *)(g + i);
+            if (extra) ev[it] = *(const f32x4 *)(extra + i);
+        }
+    }
     for (int e = threadIdx.x; e < c; e += 256) {
         double v0 = 0.0, v1 = 0.0;
         for (int k = 0; k < slots; ++k) { v0 += sums[(long)(2 * k) * c + e]; v1 += sums[(long)(2 * k + 1) * c + e]; }
@@ -491,20 +504,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restri
         if (blockIdx.x == 0) { dbeta[e] += (float)v0; dgamma[e] += (float)v1; }
     }
     __syncthreads();
-    const long base = (long)blockIdx.x * URN_APPLY_EPB;
 #pragma unroll
-    for (int it = 0; it < URN_APPLY_EPB / 1024; ++it) {
+    for (int it = 0; it < IT; ++it) {
         const long i = base + ((long)it * 256 + threadIdx.x) * 4;
-        if (i >= total) break;   // c % 4 == 0
+        if (i >= total) break;
         const int col = (int)(i % c);
-        const f32x4 xv = *(const f32x4 *)(x + i), gv = *(const f32x4 *)(g + i);
-        f32x4 ev = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (extra) ev = *(const f32x4 *)(extra + i);
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float xh = (xv[k] - s_mu[col + k]) * s_is[col + k];
-            o[k] = s_a[col + k] * (gv[k] - s_c0[col + k] - xh * s_c1[col + k]) + ev[k];
+            const float xh = (xv[it][k] - s_mu[col + k]) * s_is[col + k];
+            o[k] = s_a[col + k] * (gv[it][k] - s_c0[col + k] - xh * s_c1[col + k]) + ev[it][k];
         }
         *(f32x4 *)(dx + i) = o;
     }

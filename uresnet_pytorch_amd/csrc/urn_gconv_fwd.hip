@@ -253,7 +253,7 @@ struct Pick { int mb, nb; };
 // tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
 // before the column tile is widened
 extern long g_lds_min_wgs;
-extern int g_tile_rb, g_tile_cb;
+extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth;
 static int g_opt_dbg = 0;
 static int g_opt_fin_in_kernel = 0;
 static int g_opt_pipe = 0;
@@ -270,6 +270,8 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "gconv_dbg")) { g_opt_dbg = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_rb")) { g_tile_rb = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_cb")) { g_tile_cb = (int)value; return URN_OK; }
+    if (!strcmp(key, "tile_kc")) { g_tile_kc = (int)value; return URN_OK; }
+    if (!strcmp(key, "tile_depth")) { g_tile_depth = (int)value; return URN_OK; }
     if (!strcmp(key, "fin_in_kernel")) { g_opt_fin_in_kernel = value != 0; return URN_OK; }
     urn_set_error("urn_set_option: unknown key %s", key);
     return URN_EINVAL;

@@ -9,10 +9,12 @@
 // Arithmetic, determinism, epilogues and the partial-slab layout (one row per workgroup) are unchanged.
 #include "urn_common.h"
 #include "urn_gconv_int.h"
+#include <type_traits>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int KS, int RB, int CB, int G, int STAMP = 0>
+// ABL: timing-only ablation of the probe instantiations (1 no MFMA, 2 no global loads, 4 no LDS parking, 8 no barrier)
+template <int KS, int RB, int CB, int D, int STAMP = 0, int ABL = 0>
 __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 {
     constexpr int CIN = KS * 16;                                    // channels per step (a chunk of g.cin)
@@ -23,8 +25,8 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     __shared__ int s_idx[RB][28 * 16];
     __shared__ unsigned s_mask[RB];
     __shared__ float s_xf[2][512];                                  // folded BatchNorm affine of all input channels
-    __shared__ __attribute__((aligned(16))) float s_a[2][G][RB * 16][LDA];   // G filter offsets per step
-    __shared__ __attribute__((aligned(16))) float s_b[2][G][CB * 16][LDA];
+    __shared__ __attribute__((aligned(16))) float s_a[2][RB * 16][LDA];
+    __shared__ __attribute__((aligned(16))) float s_b[2][CB * 16][LDA];
     __shared__ double s_p[2][RB][CB * 16];
 
     const long n_out = g.n_dev ? (long)*g.n_dev : g.n_cap;
@@ -39,28 +41,23 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     const bool xs = g.xs_sums[0] != nullptr;                        // folded affine derived here from accumulated sums
     const bool xf = g.xf_scale != nullptr || xs;
 
-    // 1. table fetch (the cb == 0 wave of every row block), masks
+    // 1. table fetch (the cb == 0 wave of every row block), masks.  The table loads are issued first and consumed
+    //    after the BatchNorm coefficients below, so that the two global round trips of the prologue overlap.
+    int tv[7];
     if (cb == 0) {
-        unsigned amask = 0u;
         const long row = row_base + r;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int t = 4 * i + q;
-            int v = -1;
-            if (t < K && row < n_out) v = g.tbl[(long)t * g.ld + row];
-            s_idx[rb][i * 64 + lane] = v;  // == [t][r]
-            const unsigned long long b = __ballot(v >= 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((b >> (16 * j)) & 0xFFFFull) amask |= 1u << (4 * i + j);
+            tv[i] = -1;
+            if (t < K && row < n_out) tv[i] = g.tbl[(long)t * g.ld + row];
         }
-        if (lane == 0) s_mask[rb] = amask;
     }
     if (xs) {
         // BatchNorm statistics of the input rows: the producers accumulated (sum, sum of squares) into xs_slots rows;
         // same arithmetic as k_bn_finalize_fwd_f.  Workgroup 0 keeps the results for the backward pass.
         const bool keep = blockIdx.x == 0 && blockIdx.y == 0;
-        const double dn = (double)g.xs_n;
+        const double inv_n = g.xs_n > 0 ? 1.0 / (double)g.xs_n : 0.0;
         for (int e = tid; e < g.cin; e += T) {
             const int sl = e >= g.xs_split ? 1 : 0;
             const int ch = sl ? e - g.xs_split : e;
@@ -68,10 +65,10 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             const int ld = g.xs_ld[sl];
             double v0 = 0.0, v1 = 0.0;
             for (int k = 0; k < g.xs_slots; ++k) { v0 += p[(long)(2 * k) * ld]; v1 += p[(long)(2 * k + 1) * ld]; }
-            const double mu = g.xs_n > 0 ? v0 / dn : 0.0;
-            double var = g.xs_n > 0 ? v1 / dn - mu * mu : 0.0;
+            const double mu = v0 * inv_n;
+            double var = v1 * inv_n - mu * mu;
             if (var < 0.0) var = 0.0;
-            const double is = 1.0 / sqrt(var + g.fin_eps);
+            const double is = rsqrt(var + g.fin_eps);
             const float sc = g.xs_gamma[e] * (float)is;
             const float sh = fmaf(-(float)mu, sc, g.xs_beta[e]);
             s_xf[0][e] = sc; s_xf[1][e] = sh;
@@ -84,6 +81,19 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     } else if (xf) {
         for (int e = tid; e < g.cin; e += T) { s_xf[0][e] = g.xf_scale[e]; s_xf[1][e] = g.xf_shift[e]; }
     }
+    if (cb == 0) {
+        unsigned amask = 0u;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int v = tv[i];
+            s_idx[rb][i * 64 + lane] = v;  // == [t][r]
+            const unsigned long long b = __ballot(v >= 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((b >> (16 * j)) & 0xFFFFull) amask |= 1u << (4 * i + j);
+        }
+        if (lane == 0) s_mask[rb] = amask;
+    }
     __syncthreads();
     unsigned m = 0u;
 #pragma unroll
@@ -92,30 +102,42 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     if (g.dbg & 16) m = 0u;
 
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[G][A_F4], rb_[G][B_F4];
+    f32x4 ra[D][A_F4], rb_[D][B_F4];   // register ring: operands of the next D steps, in flight
     const int cin = g.cin, nch = cin / CIN;   // input-channel chunks per offset
     auto fetch = [&](int t, int ch, int gi) {
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int j = 0; j < A_F4; ++j) ra[gi][j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int j = 0; j < B_F4; ++j) rb_[gi][j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            return;
+        }
         const int o = g.flip ? (K - 1 - t) : t;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
-            const int e = j * T + tid;
-            if (A_TOT % T == 0 || e < A_TOT) {
-                const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
-                const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
-                ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * cin + ch * CIN + 4 * c4);
-            }
+            // threads past the end of a tile repeat its last element: every load is unconditional, so that the
+            // compiler can count the loads in flight (s_waitcnt vmcnt(N)) instead of draining them
+            const int e = (A_TOT % T == 0) ? j * T + tid : min(j * T + tid, A_TOT - 1);
+            const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
+            const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
+            ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * cin + ch * CIN + 4 * c4);
         }
         const float *wo = g.wt + ((long)o * cout + tile_col0) * cin + ch * CIN;
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
-            const int e = j * T + tid;
-            if (B_TOT % T == 0 || e < B_TOT) {
-                const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
-                rb_[gi][j] = *(const f32x4 *)(wo + (long)col * cin + 4 * c4);
-            }
+            const int e = (B_TOT % T == 0) ? j * T + tid : min(j * T + tid, B_TOT - 1);
+            const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
+            rb_[gi][j] = *(const f32x4 *)(wo + (long)col * cin + 4 * c4);
         }
     };
     auto park = [&](int t, int ch, int buf, int gi) {
+        if constexpr (ABL & 4) {   // wait for the data, write nothing
+#pragma unroll
+            for (int j = 0; j < A_F4; ++j) asm volatile("" ::"v"(ra[gi][j]));
+#pragma unroll
+            for (int j = 0; j < B_F4; ++j) asm volatile("" ::"v"(rb_[gi][j]));
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
             const int e = j * T + tid;
@@ -129,7 +151,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = have ? v[k] : 0.f;
-                *(f32x4 *)&s_a[buf][gi][row][4 * c4] = v;
+                *(f32x4 *)&s_a[buf][row][4 * c4] = v;
             }
         }
 #pragma unroll
@@ -137,39 +159,34 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             const int e = j * T + tid;
             if (B_TOT % T == 0 || e < B_TOT) {
                 const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
-                *(f32x4 *)&s_b[buf][gi][col][4 * c4] = rb_[gi][j];
+                *(f32x4 *)&s_b[buf][col][4 * c4] = rb_[gi][j];
             }
         }
     };
 
-    // 2. offset loop, G active offsets per step (a step with one 16..64-channel offset is too thin to cover a
-    //    memory round trip: 4*KS MFMAs per wave): the next group's loads are in flight during the MFMAs of the
-    //    current one; one LDS-only barrier per step
-    // a step is one (offset, channel chunk) pair; nch == 1 for cin <= 128
-    int tc[G], tn[G], cc[G], cn[G];
+    // 2. offset loop.  A step is one (active offset, channel chunk) pair; nch == 1 for cin <= 112.  A step with one
+    //    16..64-channel offset is too thin to cover a memory round trip (4*KS MFMAs per wave), so the operands of
+    //    the next D steps are kept in flight in a register ring (slot u is refilled as soon as its step has been
+    //    parked in LDS); LDS holds the current and the next step; one LDS-only barrier per step.
     int t_run = -1, c_run = 0;   // walker over (active offset, chunk)
-    auto take = [&](int (&ts)[G], int (&cs)[G]) -> int {
-        int cnt = 0;
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-            ts[gi] = -1; cs[gi] = 0;
-            if (t_run >= 0 && c_run + 1 < nch) { ++c_run; ts[gi] = t_run; cs[gi] = c_run; ++cnt; }
-            else if (m) { t_run = __builtin_ctz(m); m &= m - 1u; c_run = 0; ts[gi] = t_run; cs[gi] = 0; ++cnt; }
-            else t_run = -1;
-        }
-        return cnt;
+    auto take = [&](int &ts, int &cs) {
+        ts = -1; cs = 0;
+        if (t_run >= 0 && c_run + 1 < nch) { ++c_run; ts = t_run; cs = c_run; }
+        else if (m) { t_run = __builtin_ctz(m); m &= m - 1u; c_run = 0; ts = t_run; }
+        else t_run = -1;
     };
-    int buf = 0;
-    int n_cur = take(tc, cc);
+    int rt[D], rc[D];
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi)
-        if (tc[gi] >= 0) fetch(tc[gi], cc[gi], gi);
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi)
-        if (tc[gi] >= 0) park(tc[gi], cc[gi], 0, gi);
+    for (int i = 0; i < D; ++i) {
+        take(rt[i], rc[i]);
+        fetch(rt[i] < 0 ? 0 : rt[i], rc[i], i);   // unconditional (a dummy step past the end): see step()
+    }
+    park(rt[0] < 0 ? 0 : rt[0], rc[0], 0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    int buf = 0;
+    int ct = rt[0];   // the step whose operands are in LDS image `buf`
     unsigned long long st_fetch = 0, st_mfma = 0, st_park = 0, st_bar = 0, st_n = 0;   // STAMP build only
 #define URN_STAMP(v)                                                                          \
     unsigned long long v = 0;                                                                 \
@@ -178,21 +195,25 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");             \
         __builtin_amdgcn_sched_barrier(0);                                                    \
     }
-    while (n_cur > 0) {
+    // one step with the ring slot as a compile-time constant (register arrays must be indexed statically)
+    auto step = [&](auto slot) {
+        constexpr int u = decltype(slot)::value;
+        constexpr int nx = (u + 1) % D;   // slot of the next step
         URN_STAMP(c0)
-        const int n_next = take(tn, cn);
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi)
-            if (tn[gi] >= 0) fetch(tn[gi], cn[gi], gi);
-        URN_STAMP(c1)   // next group's global loads issued
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-            if (tc[gi] < 0 || !((my_mask >> tc[gi]) & 1u)) continue;  // wave-uniform
+        // slot u is free: its step is the one in LDS.  Loads and parks are unconditional -- past the last step they
+        // re-fetch offset 0 into a buffer nobody reads -- because a branch around a load makes the compiler drain
+        // vmcnt to 0 instead of counting the D-1 younger steps that may stay in flight.
+        take(rt[u], rc[u]);
+        fetch(rt[u] < 0 ? 0 : rt[u], rc[u], u);
+        URN_STAMP(c1)   // global loads of step +D issued
+        if ((my_mask >> ct) & 1u) {   // wave-uniform
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const f32x4 a = *(const f32x4 *)&s_a[buf][gi][rb * 16 + r][ks * 16 + 4 * q];
-                const f32x4 b = *(const f32x4 *)&s_b[buf][gi][cb * 16 + r][ks * 16 + 4 * q];
-                if ((ks + gi) & 1) {
+                const f32x4 a = *(const f32x4 *)&s_a[buf][rb * 16 + r][ks * 16 + 4 * q];
+                const f32x4 b = *(const f32x4 *)&s_b[buf][cb * 16 + r][ks * 16 + 4 * q];
+                if constexpr (ABL & 1) {
+                    asm volatile("" ::"v"(a), "v"(b));
+                } else if (ks & 1) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) acc2 = MFMA16(a[tt], b[tt], acc2);
                 } else {
@@ -202,19 +223,21 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             }
         }
         URN_STAMP(c2)   // fragment reads + MFMAs issued
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi)
-            if (tn[gi] >= 0) park(tn[gi], cn[gi], buf ^ 1, gi);
+        park(rt[nx] < 0 ? 0 : rt[nx], rc[nx], buf ^ 1, nx);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        URN_STAMP(c3)   // next group parked (includes the wait for its global data)
-        __builtin_amdgcn_s_barrier();
+        URN_STAMP(c3)   // next step parked (includes the wait for its global data)
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         URN_STAMP(c4)   // barrier passed
         if (STAMP) { st_fetch += c1 - c0; st_mfma += c2 - c1; st_park += c3 - c2; st_bar += c4 - c3; st_n += 1; }
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) { tc[gi] = tn[gi]; cc[gi] = cn[gi]; }
-        n_cur = n_next;
+        ct = rt[nx];
         buf ^= 1;
+    };
+    while (ct >= 0) {   // ct is workgroup-uniform
+        step(std::integral_constant<int, 0>());
+        if constexpr (D > 1) { if (ct < 0) break; step(std::integral_constant<int, 1>()); }
+        if constexpr (D > 2) { if (ct < 0) break; step(std::integral_constant<int, 2>()); }
+        if constexpr (D > 3) { if (ct < 0) break; step(std::integral_constant<int, 3>()); }
     }
 #undef URN_STAMP
     if (STAMP && lane == 0 && g.e_x == nullptr && g.res != nullptr) {
@@ -270,24 +293,23 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     (void)tile_row0;
 }
 
-// offsets per step.  Grouping several thin offsets into one step (G = 4 at 16 channels, 2 up to 64) was measured
-// and did not pay (cfg3 step 4.93 vs 4.56 ms: the larger LDS image costs occupancy), so G stays 1.
-template <int KS, int RB, int CB>
-constexpr int tile_group()
-{
-    return 1;
-}
+// Ring depth (steps of operands in flight per workgroup); urn_set_option("tile_depth", 2) selects the deeper ring.
+// Measured on the cfg3 shapes (tools/bench_gconv.py depth): depth 1, 2 and 4 are within 1 us of each other for every
+// layer -- the offset step is not bound by load latency but by the sum of its phases (tools/ablate_gconv.py) -- so the
+// default is the smallest kernel.
+int g_tile_depth = 0;
 
 template <int KS, int RB, int CB>
 static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
 {
     const long bx = (n_out + 16 * RB - 1) / (16 * RB);
-    constexpr int G = tile_group<KS, RB, CB>();
-    hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, G>), dim3((unsigned)bx, a.cout / (16 * CB)), dim3(64 * RB * CB), 0, st, a);
+    const dim3 grid((unsigned)bx, a.cout / (16 * CB)), block(64 * RB * CB);
+    if (g_tile_depth >= 2) hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 1>), grid, block, 0, st, a);
     return (int)bx;
 }
 
-int g_tile_rb = 0, g_tile_cb = 0;   // tuning knobs (urn_set_option "tile_rb" / "tile_cb"), 0 = automatic
+int g_tile_rb = 0, g_tile_cb = 0, g_tile_kc = 0;   // tuning knobs (urn_set_option "tile_rb" / "tile_cb" / "tile_kc"), 0 = automatic
 
 // returns the number of partial rows (workgroups along the rows), 0 when the shape has no instantiation
 template <int KS>
@@ -319,6 +341,19 @@ static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
             return (int)bx;
         }
     }
+    if ((a.dbg >> 8) && ((KS == 4 && a.cout == 64) || (KS == 1 && a.cout == 16))) {   // timing-only ablations of two shapes
+        constexpr int PRB = KS == 4 ? 2 : 4, PCB = KS == 4 ? 4 : 1;
+        if constexpr (KS == 4 || KS == 1) {
+            const long bx = (n_out + 16 * PRB - 1) / (16 * PRB);
+            const dim3 grid((unsigned)bx, 1), block(64 * PRB * PCB);
+#define URN_ABL(v) case v: hipLaunchKernelGGL((k_gconv_tile<KS, PRB, PCB, 2, 0, v>), grid, block, 0, st, a); return (int)bx;
+            switch (a.dbg >> 8) {
+                URN_ABL(1) URN_ABL(2) URN_ABL(3) URN_ABL(4) URN_ABL(6) URN_ABL(7) URN_ABL(8) URN_ABL(14) URN_ABL(15)
+            default: break;
+            }
+#undef URN_ABL
+        }
+    }
 #define URN_TL(RBv, CBv) if (rb == RBv && cb == CBv) return launch_tile2<KS, RBv, CBv>(a, n_out, st);
     URN_TL(1, 1) URN_TL(2, 1) URN_TL(4, 1) URN_TL(1, 2) URN_TL(2, 2) URN_TL(4, 2) URN_TL(1, 3) URN_TL(2, 3) URN_TL(4, 3)
     URN_TL(1, 4) URN_TL(2, 4) URN_TL(4, 4) URN_TL(1, 5) URN_TL(2, 5)
@@ -330,13 +365,16 @@ int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st)
 {
     const int nblk = a.cout / 16;
     if (a.cin > 512) return 0;   // s_xf holds 512 channels
-    // channels per step: the whole row up to 128 channels, else the largest chunk (in 16s) that divides it
+    // channels per step: the whole row up to 112 channels, else the largest chunk (in 16s, at most 7) that divides it
+    // (128 channels in one step leave LDS room for one row block only and re-read the weights per 16 rows: measured
+    // 72-93 us against 57 us in two 64-channel chunks with two row blocks at level 3, 128 -> 64)
     int kc = ks;
-    if (ks > 8) {
+    if (ks > 7) {
         kc = 1;
-        for (int d : {8, 7, 6, 5, 4, 3, 2})
+        for (int d : {7, 6, 5, 4, 3, 2})
             if (ks % d == 0) { kc = d; break; }
     }
+    if (g_tile_kc > 0 && g_tile_kc <= 8 && ks % g_tile_kc == 0) kc = g_tile_kc;
     switch (kc) {
     case 1: return launch_tile_ks<1>(a, n_out, nblk, st);
     case 2: return launch_tile_ks<2>(a, n_out, nblk, st);

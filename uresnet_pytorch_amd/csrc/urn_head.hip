@@ -249,3 +249,48 @@ extern "C" int urn_ce_bwd(const float *logits, const float *label, const float *
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
+
+// ------------------------------------------------------------------------------------ Adam on flat buffers --
+// torch.optim.Adam (reference uresnet/trainval.py:37: Adam(self._net.parameters(), lr)) over ONE contiguous
+// segment of parameters: the executor keeps parameters, gradients and both moments flat, so a step is one
+// 16-byte-per-lane streaming pass instead of a multi-tensor launch over ~190 small tensors.
+__global__ __launch_bounds__(256) void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, long n, float b1, float b2, float omb1,
+                                                   float omb2, float eps, float wd, float step_size,
+                                                   float inv_bc2_sqrt)
+{
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n && ((((uintptr_t)(p + i)) | ((uintptr_t)(g + i)) | ((uintptr_t)(m + i)) | ((uintptr_t)(v + i))) & 15) == 0) {
+        f32x4 pv = *(f32x4 *)(p + i), mv = *(f32x4 *)(m + i), vv = *(f32x4 *)(v + i);
+        const f32x4 gv = *(const f32x4 *)(g + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = fmaf(wd, pv[k], gv[k]);
+            mv[k] = fmaf(b1, mv[k], omb1 * gr);          // lerp(m, g, 1 - b1)
+            vv[k] = fmaf(b2, vv[k], omb2 * gr * gr);
+            pv[k] -= step_size * mv[k] / (sqrtf(vv[k]) * inv_bc2_sqrt + eps);
+        }
+        *(f32x4 *)(p + i) = pv; *(f32x4 *)(m + i) = mv; *(f32x4 *)(v + i) = vv;
+    } else {
+        for (long j = i; j < min(n, i + 4); ++j) {
+            const float gr = fmaf(wd, p[j], g[j]);
+            const float mm = fmaf(b1, m[j], omb1 * gr);
+            const float vv = fmaf(b2, v[j], omb2 * gr * gr);
+            m[j] = mm; v[j] = vv;
+            p[j] -= step_size * mm / (sqrtf(vv) * inv_bc2_sqrt + eps);
+        }
+    }
+}
+
+extern "C" int urn_adam_flat(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, int64_t step, void *stream)
+{
+    if (n <= 0) return URN_OK;
+    URN_CHECK_ARG(p && g && m && v && step >= 1 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1, "bad argument");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(k_adam_flat, dim3(urn_cdiv((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n,
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}

@@ -79,6 +79,8 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     'urn_bn_bwd_apply_sums': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_adam_flat': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_double, c_double, c_double, c_double,
+                              c_double, c_i64, c_void_p]),
     'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'urn_rows_scatter_add': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'urn_head_fwd': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

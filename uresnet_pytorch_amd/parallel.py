@@ -84,3 +84,90 @@ def all_reduce_scalars(values, device):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (reference uresnet/trainval.py:37) for GPU parameters whose gradients live in a
+    FlatGradients buffer: both moments are one flat buffer each and a step is one urn_adam_flat launch per
+    contiguous parameter segment (the executor's flat trunk parameters are one segment) instead of a
+    multi-tensor launch over every small tensor.  state_dict()/load_state_dict() keep torch.optim.Adam's layout
+    ({'step', 'exp_avg', 'exp_avg_sq'} per parameter), so checkpoints interchange with the reference's optimizer."""
+
+    def __init__(self, flat_grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        from . import lib
+        self._lib = lib
+        self._fg = flat_grads
+        params = flat_grads.params
+        if not params or not params[0].is_cuda:
+            raise RuntimeError('FlatAdam needs GPU parameters (use torch.optim.Adam on the CPU)')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        total = flat_grads.flat.numel()
+        self._m = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        self._v = torch.zeros_like(self._m)
+        self._step = 0
+        self._bind_state()
+        self._segments, self._seg_key = [], None
+
+    def _segment(self):
+        """maximal runs of parameters that are adjacent in memory (their gradients are adjacent by construction);
+        recomputed when the storage moved (the executor re-homes the trunk parameters at the first forward)"""
+        params = self._fg.params
+        key = (params[0].data_ptr(), params[len(params) // 2].data_ptr(), params[-1].data_ptr())
+        if key == self._seg_key:
+            return self._segments
+        segs = []
+        off = 0
+        for p in params:
+            n = p.numel()
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError('FlatAdam: fp32 contiguous parameters only')
+            last = segs[-1] if segs else None
+            if last is not None and last[0] + 4 * last[2] == p.data_ptr() and last[1] + last[2] == off:
+                last[2] += n
+            else:
+                segs.append([p.data_ptr(), off, n])
+            off += n
+        self._segments, self._seg_key = segs, key
+        return segs
+
+    def _bind_state(self):
+        off = 0
+        for p in self._fg.params:
+            n = p.numel()
+            self.state[p] = {'step': torch.tensor(float(self._step)),
+                             'exp_avg': self._m[off:off + n].view_as(p), 'exp_avg_sq': self._v[off:off + n].view_as(p)}
+            off += n
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        grp = self.param_groups[0]
+        self._step += 1
+        L = self._lib.load()
+        st = self._lib.stream()
+        g0, m0, v0 = self._fg.flat.data_ptr(), self._m.data_ptr(), self._v.data_ptr()
+        for ptr, off, n in self._segment():
+            self._lib.check(L.urn_adam_flat(ptr, g0 + 4 * off, m0 + 4 * off, v0 + 4 * off, n, float(grp['lr']),
+                                            float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']),
+                                            float(grp['weight_decay']), self._step, st))
+        return loss
+
+    def state_dict(self):
+        for p in self._fg.params:
+            self.state[p]['step'] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)      # replaces the state tensors: copy them back into the flat buffers
+        off = 0
+        steps = []
+        for p in self._fg.params:
+            n = p.numel()
+            s = self.state.get(p, {})
+            if 'exp_avg' in s:
+                self._m[off:off + n].copy_(s['exp_avg'].reshape(-1))
+                self._v[off:off + n].copy_(s['exp_avg_sq'].reshape(-1))
+                steps.append(int(float(s['step'])))
+            off += n
+        self._step = max(steps) if steps else 0
+        self._bind_state()

@@ -150,7 +150,13 @@ class trainval(object):
             self._net.eval()
         self._criterion.to(self._device)
 
-        self._optimizer = torch.optim.Adam(self._net.parameters(), lr=self._flags.LEARNING_RATE, fused=use_gpu)
+        # gradients live in one flat buffer (one memset, one all-reduce per step); on the GPU the Adam step of the
+        # reference (trainval.py:37) is one streaming pass over the flat buffers
+        self._grads = parallel.FlatGradients(self._net)
+        if use_gpu:
+            self._optimizer = parallel.FlatAdam(self._grads, lr=self._flags.LEARNING_RATE)
+        else:
+            self._optimizer = torch.optim.Adam(self._net.parameters(), lr=self._flags.LEARNING_RATE)
         self._softmax = torch.nn.Softmax(dim=1 if 'sparse' in self._flags.MODEL_NAME else 0)
 
         iteration = 0
@@ -171,5 +177,4 @@ class trainval(object):
             iteration = checkpoint['global_step'] + 1
             print('Done.')
         parallel.broadcast_parameters(self._net)
-        self._grads = parallel.FlatGradients(self._net)
         return iteration
