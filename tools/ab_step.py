@@ -17,10 +17,10 @@ crit = SparseSegmentationLoss(flags)
 variants = {}
 from uresnet_pytorch_amd import lib as _lib
 L = _lib.load()
-for name, fl in (('fused, accumulated stats', 0), ('fused, slab stats', 4), ('unfused', 1)):
+for name, fl in (('default (fused, accumulated stats)', 0), ('slab stats', 4), ('single stream', 2), ('unfused', 1)):
     torch.manual_seed(0)
     net = SparseUResNet(flags).to(dev).train(); net.executor_flags = fl
-    g = parallel.FlatGradients(net); opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    g = parallel.FlatGradients(net); opt = parallel.FlatAdam(g, lr=1e-3)
     def step(net=net, g=g, opt=opt):
         g.zero(); out = net(data); loss, _ = crit(out, [data], [label], None); loss.backward(); opt.step()
     variants[name] = step

@@ -50,5 +50,13 @@ for lv, ci, co in shapes:
         out.append('%s %.0f' % (name, t))
     fl = 2.0 * geo.rules[lv] * ci * co
     tdw = min(run_dw(lv, ci, co) for _ in range(3))
+    if len(sys.argv) > 1 and sys.argv[1] == 'dw':
+        outs = []
+        for nb in (512, 1024, 2048, 4096, 8192):
+            L.urn_set_option(b'dw_blocks', nb)
+            outs.append('%d: %.0f' % (nb, min(run_dw(lv, ci, co) for _ in range(3))))
+        L.urn_set_option(b'dw_blocks', 2048)
+        print('L%d %3d->%3d dW us by target blocks  %s' % (lv, ci, co, ' | '.join(outs)))
+        continue
     L.urn_set_option(b'tile_rb', 0); L.urn_set_option(b'tile_cb', 0); L.urn_set_option(b'tile_kc', 0)
     print('L%d %3d->%3d n=%6d fwd %s us | dW %.0f us (%.1f TF)' % (lv, ci, co, geo.n[lv], ' | '.join(out), tdw, fl / tdw / 1e6))

@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void k_gconv_dw_small(const float *__restrict_
     }
 }
 
+int g_dw_blocks = 2048;   // target number of workgroups of the weight-gradient kernel (urn_set_option "dw_blocks")
+
 extern "C" int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *tbl, int64_t ld, int K,
                                 int64_t n_out, int cin, int cout, float *dw, void *stream)
 {
@@ -248,7 +250,7 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
     }
     const int n_ci_tiles = urn_cdiv(cin, DW_MAXI * 16), n_co_tiles = urn_cdiv(cout, DW_MAXN * 16);
     // aim for ~2048 blocks, chunks of at least 256 rows (multiple of 256)
-    int chunks = 2048 / (K * n_ci_tiles * n_co_tiles);
+    int chunks = g_dw_blocks / (K * n_ci_tiles * n_co_tiles);
     if (chunks < 1) chunks = 1;
     long chunk = (n_out + chunks - 1) / chunks;
     if (chunk < 256) chunk = 256;
