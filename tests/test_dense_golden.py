@@ -84,3 +84,43 @@ def test_dense_model_gpu_route_matches_reference_golden(name):
             p = dict(net.named_parameters())[k[5:]]
             worst = max(worst, rel(p.grad.cpu().numpy(), g[k]))
     assert worst < 3e-2, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,uns,B', [(32, 3, 2), (64, 4, 1)])
+def test_dense_gpu_route_mfma_channels_vs_cpu_route(S, uns, B):
+    """BASELINE configs[1] topology (-dd 3 -uf 16: channel counts 16..256, the MFMA gather-conv kernels incl. channel
+    chunking) at reduced spatial size: GPU route against the CPU route of the same module, which the golden vectors
+    above pin to the reference.  Forward/loss 2e-5; end-to-end gradients 3e-2 (ReLU-mask flips, see above)."""
+    from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+    dev = torch.device('cuda:0')
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=uns, SPATIAL_SIZE=S, NUM_CLASS=5,
+                            BN_MOMENTUM=0.9)
+    torch.manual_seed(1)
+    cpu = DenseUResNet(flags).train()
+    gpu = DenseUResNet(flags).to(dev).train()
+    gpu.load_state_dict(cpu.state_dict())
+    blob = make_dense_blob(list(range(B)), S, 3)
+    x, lab = torch.from_numpy(blob['data']), torch.from_numpy(blob['label'])
+    crit = DenseSegmentationLoss(flags)
+    out_c = cpu(x); loss_c, acc_c = crit(list(out_c), list(x), list(lab), None); loss_c.backward()
+    xg, lg = x.to(dev), lab.to(dev)
+    out_g = gpu(xg); loss_g, acc_g = crit(list(out_g), list(xg), list(lg), None); loss_g.backward()
+    assert rel(out_g.detach().cpu().numpy(), out_c.detach().numpy()) < 2 * TOL
+    assert abs(loss_g.item() - loss_c.item()) < 2 * TOL * abs(loss_c.item())
+    assert abs(acc_g - acc_c) < 1e-4
+    # gradients that are structurally zero (a conv bias or a BatchNorm shift that the next batch-statistics BatchNorm
+    # removes again) are cancellation noise in both routes: errors are measured against max(|ref|, 1e-4 of the largest
+    # parameter-gradient norm)
+    worst, worst_k = 0.0, None
+    pc = dict(cpu.named_parameters())
+    floor = 1e-4 * max(float(p.grad.norm()) for p in pc.values() if p.grad is not None)
+    for k, p in gpu.named_parameters():
+        assert (p.grad is None) == (pc[k].grad is None), k
+        if p.grad is None:
+            continue
+        ref = pc[k].grad.numpy().astype(np.float64)
+        e = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - ref) / max(np.linalg.norm(ref), floor)
+        if e > worst:
+            worst, worst_k = e, k
+    assert worst < 3e-2, (worst_k, worst)
