@@ -17,7 +17,7 @@ crit = SparseSegmentationLoss(flags)
 variants = {}
 from uresnet_pytorch_amd import lib as _lib
 L = _lib.load()
-for name, fl in (('default (fused, accumulated stats)', 0), ('slab stats', 4), ('single stream', 2), ('unfused', 1)):
+for name, fl in (('default', 0), ('slab stats', 4)):
     torch.manual_seed(0)
     net = SparseUResNet(flags).to(dev).train(); net.executor_flags = fl
     g = parallel.FlatGradients(net); opt = parallel.FlatAdam(g, lr=1e-3)
@@ -27,11 +27,11 @@ for name, fl in (('default (fused, accumulated stats)', 0), ('slab stats', 4), (
 for s in variants.values():
     for _ in range(5): s()
 res = {k: [] for k in variants}
-kernels = {'tile2d(6)': 6}
+kernels = {'interleaved': 1, 'plain': 0}
 res = {(k, kn): [] for k in variants for kn in kernels}
 for rnd in range(4):
     for kn, kv in kernels.items():
-        L.urn_set_option(b'gconv_kernel', kv)
+        L.urn_set_option(b'tile_il', kv)
         for k, s in variants.items():
             for _ in range(2): s()
             torch.cuda.synchronize(); t0 = time.perf_counter()

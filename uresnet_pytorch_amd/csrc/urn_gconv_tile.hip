@@ -14,7 +14,9 @@
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // ABL: timing-only ablation of the probe instantiations (1 no MFMA, 2 no global loads, 4 no LDS parking, 8 no barrier)
-template <int KS, int RB, int CB, int D, int STAMP = 0, int ABL = 0>
+// IL: straight-line step (no branches) with the loads of step +2 and the parking of step +1 interleaved between the
+//     MFMAs of the current step; 1 = plain input rows, 2 = relu(x*scale+shift) on the input rows.  Needs D == 2.
+template <int KS, int RB, int CB, int D, int STAMP = 0, int ABL = 0, int IL = 0>
 __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 {
     constexpr int CIN = KS * 16;                                    // channels per step (a chunk of g.cin)
@@ -233,7 +235,115 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         ct = rt[nx];
         buf ^= 1;
     };
-    while (ct >= 0) {   // ct is workgroup-uniform
+    // --- interleaved variant -------------------------------------------------------------------------------------
+    // Everything of a step that is not an MFMA (address arithmetic and global loads of step +2, BatchNorm/ReLU and
+    // zero-fill plus the LDS writes of step +1, fragment reads of this step) is cut into pieces and placed between
+    // the MFMAs of this step, in one basic block: the matrix pipe of a SIMD is then fed while its waves do the
+    // bookkeeping, instead of all waves of the workgroup alternating between a bookkeeping phase and an MFMA phase.
+    auto piece_fetch_a = [&](int t, int ch, auto slot, auto jj) {
+        constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
+        const int e = (A_TOT % T == 0) ? j * T + tid : min(j * T + tid, A_TOT - 1);
+        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
+        const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
+        ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * cin + ch * CIN + 4 * c4);
+    };
+    auto piece_fetch_b = [&](int t, int ch, auto slot, auto jj) {
+        constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
+        const int o = g.flip ? (K - 1 - t) : t;
+        const float *wo = g.wt + ((long)o * cout + tile_col0) * cin + ch * CIN;
+        const int e = (B_TOT % T == 0) ? j * T + tid : min(j * T + tid, B_TOT - 1);
+        const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
+        rb_[gi][j] = *(const f32x4 *)(wo + (long)col * cin + 4 * c4);
+    };
+    auto piece_park_a = [&](int t, int ch, int pbuf, auto slot, auto jj) {
+        constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
+        const int e = (A_TOT % T == 0) ? j * T + tid : min(j * T + tid, A_TOT - 1);   // duplicates rewrite the same value
+        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
+        const bool have = s_idx[row >> 4][t * 16 + (row & 15)] >= 0;
+        f32x4 v = ra[gi][j];
+        if constexpr (IL == 2) {
+            const f32x4 sc = *(const f32x4 *)&s_xf[0][ch * CIN + 4 * c4], sh = *(const f32x4 *)&s_xf[1][ch * CIN + 4 * c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = have ? v[k] : 0.f;
+        *(f32x4 *)&s_a[pbuf][row][4 * c4] = v;
+    };
+    auto piece_park_b = [&](int pbuf, auto slot, auto jj) {
+        constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
+        const int e = (B_TOT % T == 0) ? j * T + tid : min(j * T + tid, B_TOT - 1);
+        const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
+        *(f32x4 *)&s_b[pbuf][col][4 * c4] = rb_[gi][j];
+    };
+    auto step_il = [&](auto slot) {
+        constexpr int u = decltype(slot)::value;
+        constexpr int nx = (u + 1) % D;
+        using SU = std::integral_constant<int, u>;
+        using SN = std::integral_constant<int, nx>;
+        // next-next step (branch-free walker; past the end it repeats offset 0, whose operands nobody reads)
+        {
+            const bool stay = t_run >= 0 && c_run + 1 < nch;
+            const bool pop = !stay && m != 0u;
+            const int nt = pop ? __builtin_ctz(m | 0x80000000u) : (stay ? t_run : -1);
+            m = pop ? (m & (m - 1u)) : m;
+            c_run = stay ? c_run + 1 : 0;
+            t_run = nt;
+            rt[u] = nt; rc[u] = c_run;
+        }
+        const int tf = rt[u] < 0 ? 0 : rt[u], cf = rc[u];         // to fetch into slot u
+        const int tp = rt[nx] < 0 ? 0 : rt[nx], cp = rc[nx];      // to park from slot nx
+        const int pbuf = buf ^ 1;
+        constexpr int NP = 2 * (A_F4 + B_F4);                      // pieces: fetch A.., fetch B.., park A.., park B..
+        auto piece = [&](auto pi) {
+            constexpr int i = decltype(pi)::value;
+            if constexpr (i < A_F4) piece_fetch_a(tf, cf, SU(), std::integral_constant<int, i>());
+            else if constexpr (i < A_F4 + B_F4) piece_fetch_b(tf, cf, SU(), std::integral_constant<int, i - A_F4>());
+            else if constexpr (i < 2 * A_F4 + B_F4) piece_park_a(tp, cp, pbuf, SN(), std::integral_constant<int, i - A_F4 - B_F4>());
+            else if constexpr (i < NP) piece_park_b(pbuf, SN(), std::integral_constant<int, i - 2 * A_F4 - B_F4>());
+        };
+        constexpr int PER = (NP + KS - 1) / KS;                    // pieces after each group of four MFMAs
+        auto group = [&](auto kk) {
+            constexpr int ks = decltype(kk)::value;
+            const f32x4 a = *(const f32x4 *)&s_a[buf][rb * 16 + r][ks * 16 + 4 * q];
+            const f32x4 b = *(const f32x4 *)&s_b[buf][cb * 16 + r][ks * 16 + 4 * q];
+            // two accumulators, alternating per MFMA: consecutive MFMAs are independent (measured 22 vs 24 us at
+            // level 3, 64 -> 64, against one accumulator per group of four)
+            acc = MFMA16(a[0], b[0], acc); acc2 = MFMA16(a[1], b[1], acc2);
+            acc = MFMA16(a[2], b[2], acc); acc2 = MFMA16(a[3], b[3], acc2);
+            if constexpr (ks * PER + 0 < NP) piece(std::integral_constant<int, ks * PER + 0>());
+            if constexpr (PER > 1 && ks * PER + 1 < NP) piece(std::integral_constant<int, ks * PER + 1>());
+            if constexpr (PER > 2 && ks * PER + 2 < NP) piece(std::integral_constant<int, ks * PER + 2>());
+            if constexpr (PER > 3 && ks * PER + 3 < NP) piece(std::integral_constant<int, ks * PER + 3>());
+            if constexpr (PER > 4 && ks * PER + 4 < NP) piece(std::integral_constant<int, ks * PER + 4>());
+            if constexpr (PER > 5 && ks * PER + 5 < NP) piece(std::integral_constant<int, ks * PER + 5>());
+#if 0  // pinning the pieces to their group with sched_barrier(0) measured 5-15 % slower than the free schedule
+            __builtin_amdgcn_sched_barrier(0);   // keep the pieces with their MFMA group
+#endif
+        };
+        group(std::integral_constant<int, 0>());
+        if constexpr (KS > 1) group(std::integral_constant<int, 1>());
+        if constexpr (KS > 2) group(std::integral_constant<int, 2>());
+        if constexpr (KS > 3) group(std::integral_constant<int, 3>());
+        if constexpr (KS > 4) group(std::integral_constant<int, 4>());
+        if constexpr (KS > 5) group(std::integral_constant<int, 5>());
+        if constexpr (KS > 6) group(std::integral_constant<int, 6>());
+        if constexpr (KS > 7) group(std::integral_constant<int, 7>());
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ct = rt[nx];
+        buf ^= 1;
+    };
+    if constexpr (IL != 0 && D == 2) {
+        static_assert(2 * (A_F4 + B_F4) <= 6 * KS, "too many pieces for the interleave table");
+        while (ct >= 0) {
+            step_il(std::integral_constant<int, 0>());
+            if (ct < 0) break;
+            step_il(std::integral_constant<int, 1>());
+        }
+    }
+    while (IL == 0 && ct >= 0) {   // ct is workgroup-uniform
         step(std::integral_constant<int, 0>());
         if constexpr (D > 1) { if (ct < 0) break; step(std::integral_constant<int, 1>()); }
         if constexpr (D > 2) { if (ct < 0) break; step(std::integral_constant<int, 2>()); }
@@ -298,12 +408,22 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 // layer -- the offset step is not bound by load latency but by the sum of its phases (tools/ablate_gconv.py) -- so the
 // default is the smallest kernel.
 int g_tile_depth = 0;
+int g_tile_il = 1;            // interleaved step for KS >= URN_IL_MIN_KS (urn_set_option("tile_il", 0) = plain step)
+#define URN_IL_MIN_KS 2
 
 template <int KS, int RB, int CB>
 static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
 {
     const long bx = (n_out + 16 * RB - 1) / (16 * RB);
     const dim3 grid((unsigned)bx, a.cout / (16 * CB)), block(64 * RB * CB);
+    if constexpr (KS >= URN_IL_MIN_KS) {
+        if (g_tile_il) {
+            const bool xfm = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
+            if (xfm) hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2, 0, 0, 2>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2, 0, 0, 1>), grid, block, 0, st, a);
+            return (int)bx;
+        }
+    }
     if (g_tile_depth >= 2) hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 1>), grid, block, 0, st, a);
     return (int)bx;
