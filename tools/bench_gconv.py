@@ -40,8 +40,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'il':
 if len(sys.argv) > 1 and sys.argv[1] == 'depth':
     variants = [('d%d' % d, (0, 0, 0, d)) for d in (1, 2, 4)]
 if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
-    shapes = [(3, 128, 64), (2, 96, 48), (1, 64, 32), (0, 32, 16), (3, 64, 128), (2, 48, 96), (1, 32, 64), (0, 16, 32), (3, 64, 64), (4, 160, 80)]
-    variants = [('auto', (0, 0, 0))] + [('%dx%d/k%d' % (r, c, k), (r, c, k)) for k in (2, 3, 4, 8) for r in (1, 2, 4) for c in (1, 2, 3, 4)]
+    shapes = [(1, 32, 32), (2, 48, 48), (3, 64, 64), (4, 80, 80), (3, 128, 64), (2, 96, 48), (1, 64, 32), (3, 64, 128), (2, 48, 96), (1, 32, 64), (4, 160, 80), (4, 80, 160)]
+    variants = [('auto', (0, 0, 0))] + [('%dx%d/k%d' % (r, c, k), (r, c, k)) for k in (2, 3, 4, 5) for r in (1, 2, 4) for c in (1, 2, 3, 4, 5)]
 for lv, ci, co in shapes:
     out = []
     for name, mw in variants:

@@ -181,6 +181,205 @@ __global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, c
     }
 }
 
+// Second form of the weight gradient (default): same tiling and arithmetic, restructured after the findings on the
+// forward kernel (tools/ablate_gconv.py): (1) the valid pairs of up to 1024 candidate rows are compacted in ONE pass
+// (four table loads in flight per thread, two block barriers) instead of one pass per 256 rows with a carried remainder;
+// (2) the batch loop is straight-line code -- loads of batch +2 into a two-slot register ring, parking of batch +1 and
+// the MFMAs of the current batch in one basic block, every load unconditional (clamped pair index) so that the
+// compiler counts them (s_waitcnt vmcnt(N)) and interleaves everything with the MFMAs; one LDS-only barrier per batch.
+// S = output blocks per wave (ceil(blocks / 4)), XF = the conv input was relu(x*scale + shift).
+#define DW2_LIST 1024
+#include <type_traits>
+template <int S, int XF>
+__global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, const float *__restrict__ xf_scale,
+                                                   const float *__restrict__ xf_shift, const float *__restrict__ dy,
+                                                   const int *__restrict__ tbl, long ld, long n_out, int cin,
+                                                   int cout, long chunk, int n_ci_tiles,
+                                                   float *__restrict__ dw)
+{
+    __shared__ int s_in[DW2_LIST], s_out[DW2_LIST];
+    __shared__ int s_cnt[16];
+    __shared__ __attribute__((aligned(16))) float s_a[2][DW_KT][DW_MAXI * 16 + 16];
+    __shared__ __attribute__((aligned(16))) float s_b[2][DW_KT][DW_MAXN * 16 + 32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int o = blockIdx.y;
+    const int ci_tile = blockIdx.z % n_ci_tiles, co_tile = blockIdx.z / n_ci_tiles;
+    const int ci0 = ci_tile * DW_MAXI * 16, co0 = co_tile * DW_MAXN * 16;
+    const int ci_w = min(DW_MAXI * 16, cin - ci0), co_w = min(DW_MAXN * 16, cout - co0);
+    const int mi_n = ci_w / 16, ni_n = co_w / 16, nblk = mi_n * ni_n;
+
+    f32x4 acc[S];
+    int mi_[S], ni_[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int blk = min(wave + 4 * s, nblk - 1);   // past the last block: recompute it (its result is not flushed)
+        mi_[s] = blk / ni_n; ni_[s] = blk - mi_[s] * ni_n;
+    }
+    // what this thread moves per batch: two 16-byte pieces of the x rows, three of the dy rows
+    const int a_tot = DW_KT * (ci_w / 4), b_tot = DW_KT * (co_w / 4);
+    int a_rr[2], a_c4[2], b_rr[3], b_c4[3];
+    f32x4 xsc[2], xsh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = min(j * 256 + tid, a_tot - 1);
+        a_rr[j] = e / (ci_w / 4); a_c4[j] = e - a_rr[j] * (ci_w / 4);
+        if (XF) { xsc[j] = *(const f32x4 *)(xf_scale + ci0 + 4 * a_c4[j]); xsh[j] = *(const f32x4 *)(xf_shift + ci0 + 4 * a_c4[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int e = min(j * 256 + tid, b_tot - 1);
+        b_rr[j] = e / (co_w / 4); b_c4[j] = e - b_rr[j] * (co_w / 4);
+    }
+    f32x4 ra[2][2], rb[2][3];   // register ring: two batches in flight
+
+    const long row_begin = (long)blockIdx.x * chunk;
+    const long row_end = min(n_out, row_begin + chunk);
+    for (long sub = row_begin; sub < row_end; sub += DW2_LIST) {
+        // ---- phase A: compact the valid (in, out) pairs of up to 1024 rows, row order preserved ----
+        const long sub_end = min(row_end, sub + DW2_LIST);
+        int idx[4];
+        unsigned long long bal[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = sub + r * 256 + tid;
+            idx[r] = row < sub_end ? tbl[(long)o * ld + row] : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bal[r] = __ballot(idx[r] >= 0);
+            if (lane == 0) s_cnt[r * 4 + wave] = __popcll(bal[r]);
+        }
+        __syncthreads();
+        int cnt = 0;
+        int base[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int v = s_cnt[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i < r * 4 + wave) base[r] += v;
+            cnt += v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (idx[r] >= 0) {
+                const int p = base[r] + __popcll(bal[r] & ((1ull << lane) - 1ull));
+                s_in[p] = idx[r];
+                s_out[p] = (int)(sub + r * 256 + tid);
+            }
+        __syncthreads();
+        if (cnt == 0) continue;   // block-uniform
+        const int nbatch = (cnt + DW_KT - 1) / DW_KT;
+
+        // ---- phase B: batches of 32 pairs ----
+        auto fetch_a = [&](int b, auto slot, auto jj) {
+            constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
+            const int p = min(b * DW_KT + a_rr[j], cnt - 1);   // past the end: the last pair again (zero-filled when parked)
+            ra[u][j] = *(const f32x4 *)(x + (long)s_in[p] * cin + ci0 + 4 * a_c4[j]);
+        };
+        auto fetch_b = [&](int b, auto slot, auto jj) {
+            constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
+            const int p = min(b * DW_KT + b_rr[j], cnt - 1);
+            rb[u][j] = *(const f32x4 *)(dy + (long)s_out[p] * cout + co0 + 4 * b_c4[j]);
+        };
+        auto park_a = [&](int b, int buf, auto slot, auto jj) {
+            constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
+            const int nb = cnt - b * DW_KT;
+            f32x4 v = ra[u][j];
+            if (XF) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], xsc[j][k], xsh[j][k]), 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = a_rr[j] < nb ? v[k] : 0.f;   // zero-fill the tail of the last batch
+            *(f32x4 *)&s_a[buf][a_rr[j]][4 * a_c4[j]] = v;
+        };
+        auto park_b = [&](int b, int buf, auto slot, auto jj) {
+            constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
+            const int nb = cnt - b * DW_KT;
+            f32x4 v = rb[u][j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = b_rr[j] < nb ? v[k] : 0.f;
+            *(f32x4 *)&s_b[buf][b_rr[j]][4 * b_c4[j]] = v;
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        fetch_a(0, I0(), I0()); fetch_a(0, I0(), I1()); fetch_b(0, I0(), I0()); fetch_b(0, I0(), I1()); fetch_b(0, I0(), I2());
+        fetch_a(1, I1(), I0()); fetch_a(1, I1(), I1()); fetch_b(1, I1(), I0()); fetch_b(1, I1(), I1()); fetch_b(1, I1(), I2());
+        park_a(0, 0, I0(), I0()); park_a(0, 0, I0(), I1()); park_b(0, 0, I0(), I0()); park_b(0, 0, I0(), I1()); park_b(0, 0, I0(), I2());
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // one batch: MFMAs of batch b (LDS image b & 1), loads of batch b+2 into slot U, parking of batch b+1 from slot U^1
+        auto step = [&](int b, auto slot) {
+            constexpr int U = decltype(slot)::value;
+            using SU = std::integral_constant<int, U>;
+            using SN = std::integral_constant<int, U ^ 1>;
+            const int buf = b & 1;
+            auto piece = [&](auto pi) {
+                constexpr int i = decltype(pi)::value;
+                if constexpr (i == 0) fetch_a(b + 2, SU(), I0());
+                else if constexpr (i == 1) fetch_a(b + 2, SU(), I1());
+                else if constexpr (i == 2) fetch_b(b + 2, SU(), I0());
+                else if constexpr (i == 3) fetch_b(b + 2, SU(), I1());
+                else if constexpr (i == 4) fetch_b(b + 2, SU(), I2());
+                else if constexpr (i == 5) park_a(b + 1, buf ^ 1, SN(), I0());
+                else if constexpr (i == 6) park_a(b + 1, buf ^ 1, SN(), I1());
+                else if constexpr (i == 7) park_b(b + 1, buf ^ 1, SN(), I0());
+                else if constexpr (i == 8) park_b(b + 1, buf ^ 1, SN(), I1());
+                else if constexpr (i == 9) park_b(b + 1, buf ^ 1, SN(), I2());
+            };
+            constexpr int PER = (10 + S - 1) / S;
+            auto group = [&](auto ss) {
+                constexpr int sl = decltype(ss)::value;
+#pragma unroll
+                for (int ks = 0; ks < DW_KT / 4; ++ks) {
+                    const float av = s_a[buf][4 * ks + q][mi_[sl] * 16 + m];
+                    const float bv = s_b[buf][4 * ks + q][ni_[sl] * 16 + m];
+                    acc[sl] = MFMA16(av, bv, acc[sl]);
+                }
+                if constexpr (sl * PER + 0 < 10) piece(std::integral_constant<int, sl * PER + 0>());
+                if constexpr (PER > 1 && sl * PER + 1 < 10) piece(std::integral_constant<int, sl * PER + 1>());
+                if constexpr (PER > 2 && sl * PER + 2 < 10) piece(std::integral_constant<int, sl * PER + 2>());
+                if constexpr (PER > 3 && sl * PER + 3 < 10) piece(std::integral_constant<int, sl * PER + 3>());
+                if constexpr (PER > 4 && sl * PER + 4 < 10) piece(std::integral_constant<int, sl * PER + 4>());
+                if constexpr (PER > 5 && sl * PER + 5 < 10) piece(std::integral_constant<int, sl * PER + 5>());
+                if constexpr (PER > 6 && sl * PER + 6 < 10) piece(std::integral_constant<int, sl * PER + 6>());
+                if constexpr (PER > 7 && sl * PER + 7 < 10) piece(std::integral_constant<int, sl * PER + 7>());
+                if constexpr (PER > 8 && sl * PER + 8 < 10) piece(std::integral_constant<int, sl * PER + 8>());
+                if constexpr (PER > 9 && sl * PER + 9 < 10) piece(std::integral_constant<int, sl * PER + 9>());
+            };
+            group(I0());
+            if constexpr (S > 1) group(I1());
+            if constexpr (S > 2) group(I2());
+            if constexpr (S > 3) group(std::integral_constant<int, 3>());
+            if constexpr (S > 4) group(std::integral_constant<int, 4>());
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        for (int b = 0; b < nbatch; b += 2) {
+            step(b, I0());
+            if (b + 1 < nbatch) step(b + 1, I1());
+        }
+    }
+    // accumulate this block's partial into dw[o][ci][co]; C layout: col = lane&15, row = q*4+i
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (wave + 4 * s < nblk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ci = ci0 + mi_[s] * 16 + q * 4 + i, co = co0 + ni_[s] * 16 + m;
+                atomicAdd(&dw[((long)o * cin + ci) * cout + co], acc[s][i]);
+            }
+        }
+    }
+}
+
 // VALU weight gradient for channel counts that are not multiples of 16 (the 1-channel stem).
 // grid (chunks, K); 256 threads = (cin*cout) pairs x R row lanes; LDS reduction over the row lanes,
 // one atomic per (pair, block).
@@ -221,6 +420,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw_small(const float *__restrict_
     }
 }
 
+int g_dw_kernel = 2;      // 2 = k_gconv_dw2 (default), 1 = k_gconv_dw (urn_set_option "dw_kernel")
 int g_dw_blocks = 2048;   // target number of workgroups of the weight-gradient kernel (urn_set_option "dw_blocks")
 
 extern "C" int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *tbl, int64_t ld, int K,
@@ -258,8 +458,23 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
     chunks = (int)((n_out + chunk - 1) / chunk);
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_DW, st);
-    hipLaunchKernelGGL(k_gconv_dw, dim3(chunks, K, n_ci_tiles * n_co_tiles), dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,
-                       (long)n_out, cin, cout, chunk, n_ci_tiles, dw);
+    const dim3 grid(chunks, K, n_ci_tiles * n_co_tiles);
+    if (g_dw_kernel == 2) {
+        const int ci_w = cin < DW_MAXI * 16 ? cin : DW_MAXI * 16, co_w = cout < DW_MAXN * 16 ? cout : DW_MAXN * 16;
+        const int slots = ((ci_w / 16) * (co_w / 16) + 3) / 4;   // of the widest tile
+#define URN_DW2(Sv)                                                                                                              \
+    case Sv:                                                                                                                     \
+        if (xf_scale) hipLaunchKernelGGL((k_gconv_dw2<Sv, 1>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
+                                         (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                                        \
+        else hipLaunchKernelGGL((k_gconv_dw2<Sv, 0>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,          \
+                                (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                                                 \
+        break;
+        switch (slots) { URN_DW2(1) URN_DW2(2) URN_DW2(3) URN_DW2(4) URN_DW2(5) default: break; }
+#undef URN_DW2
+    } else {
+        hipLaunchKernelGGL(k_gconv_dw, grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,
+                           (long)n_out, cin, cout, chunk, n_ci_tiles, dw);
+    }
     if (prof) urn_prof_end(st);
     URN_LAUNCH_CHECK();
     return URN_OK;

@@ -13,6 +13,16 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// f(integral_constant<I>) for I in [B, E): loop bodies that index register arrays need compile-time indices
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>());
+        static_for<B + 1, E>(f);
+    }
+}
+
 // ABL: timing-only ablation of the probe instantiations (1 no MFMA, 2 no global loads, 4 no LDS parking, 8 no barrier)
 // IL: straight-line step (no branches) with the loads of step +2 and the parking of step +1 interleaved between the
 //     MFMAs of the current step; 1 = plain input rows, 2 = relu(x*scale+shift) on the input rows.  Needs D == 2.
@@ -302,7 +312,10 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             else if constexpr (i < 2 * A_F4 + B_F4) piece_park_a(tp, cp, pbuf, SN(), std::integral_constant<int, i - A_F4 - B_F4>());
             else if constexpr (i < NP) piece_park_b(pbuf, SN(), std::integral_constant<int, i - 2 * A_F4 - B_F4>());
         };
-        constexpr int PER = (NP + KS - 1) / KS;                    // pieces after each group of four MFMAs
+        // (issuing all loads first behind a sched_barrier, or pinning the pieces to their group, measured 5-15 % slower
+        // than leaving the order inside the block to the compiler)
+        constexpr int P0 = 0;
+        constexpr int PER = (NP - P0 + KS - 1) / KS;               // pieces after each group of four MFMAs
         auto group = [&](auto kk) {
             constexpr int ks = decltype(kk)::value;
             const f32x4 a = *(const f32x4 *)&s_a[buf][rb * 16 + r][ks * 16 + 4 * q];
@@ -311,24 +324,9 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             // level 3, 64 -> 64, against one accumulator per group of four)
             acc = MFMA16(a[0], b[0], acc); acc2 = MFMA16(a[1], b[1], acc2);
             acc = MFMA16(a[2], b[2], acc); acc2 = MFMA16(a[3], b[3], acc2);
-            if constexpr (ks * PER + 0 < NP) piece(std::integral_constant<int, ks * PER + 0>());
-            if constexpr (PER > 1 && ks * PER + 1 < NP) piece(std::integral_constant<int, ks * PER + 1>());
-            if constexpr (PER > 2 && ks * PER + 2 < NP) piece(std::integral_constant<int, ks * PER + 2>());
-            if constexpr (PER > 3 && ks * PER + 3 < NP) piece(std::integral_constant<int, ks * PER + 3>());
-            if constexpr (PER > 4 && ks * PER + 4 < NP) piece(std::integral_constant<int, ks * PER + 4>());
-            if constexpr (PER > 5 && ks * PER + 5 < NP) piece(std::integral_constant<int, ks * PER + 5>());
-#if 0  // pinning the pieces to their group with sched_barrier(0) measured 5-15 % slower than the free schedule
-            __builtin_amdgcn_sched_barrier(0);   // keep the pieces with their MFMA group
-#endif
+            static_for<P0 + ks * PER, (P0 + (ks + 1) * PER < NP ? P0 + (ks + 1) * PER : NP)>(piece);
         };
-        group(std::integral_constant<int, 0>());
-        if constexpr (KS > 1) group(std::integral_constant<int, 1>());
-        if constexpr (KS > 2) group(std::integral_constant<int, 2>());
-        if constexpr (KS > 3) group(std::integral_constant<int, 3>());
-        if constexpr (KS > 4) group(std::integral_constant<int, 4>());
-        if constexpr (KS > 5) group(std::integral_constant<int, 5>());
-        if constexpr (KS > 6) group(std::integral_constant<int, 6>());
-        if constexpr (KS > 7) group(std::integral_constant<int, 7>());
+        static_for<0, KS>(group);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -336,7 +334,6 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         buf ^= 1;
     };
     if constexpr (IL != 0 && D == 2) {
-        static_assert(2 * (A_F4 + B_F4) <= 6 * KS, "too many pieces for the interleave table");
         while (ct >= 0) {
             step_il(std::integral_constant<int, 0>());
             if (ct < 0) break;
@@ -443,7 +440,7 @@ static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
     int rb = 0, cb = 0;
     for (int c = (nblk <= 5 ? nblk : 4); c >= 1 && !rb; --c) {
         if (nblk % c) continue;
-        for (int cand : {4, 2, 1}) {
+        for (int cand : {KS == 2 ? 2 : 4, KS == 2 ? 4 : 2, 1}) {   // 32-channel steps: two row blocks measured 10-15 % faster than four
             if (!lds_ok(cand, c)) continue;
             if (cand > 1 && (blocks16 / cand) * (nblk / c) < 100) continue;
             rb = cand; cb = c;
