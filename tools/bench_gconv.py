@@ -37,6 +37,8 @@ variants = [('auto', (0, 0, 0))]
 if len(sys.argv) > 1 and sys.argv[1] == 'il':
     variants = [('plain', (0, 0, 0, 0, 0)), ('interleaved', (0, 0, 0, 0, 1))]
     shapes = [(0, 16, 16), (1, 32, 32), (0, 32, 16), (0, 16, 32), (1, 16, 32), (1, 32, 64), (2, 32, 48)] + shapes[2:5]
+if len(sys.argv) > 1 and sys.argv[1] == 'xcd':
+    variants = [('xcd-aware', (0, 0, 0, 0, 1, 0)), ('round-robin', (0, 0, 0, 0, 1, 64))]
 if len(sys.argv) > 1 and sys.argv[1] == 'depth':
     variants = [('d%d' % d, (0, 0, 0, d)) for d in (1, 2, 4)]
 if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
@@ -48,6 +50,7 @@ for lv, ci, co in shapes:
         L.urn_set_option(b'gconv_kernel', 6); L.urn_set_option(b'tile_rb', mw[0]); L.urn_set_option(b'tile_cb', mw[1]); L.urn_set_option(b'tile_kc', mw[2])
         L.urn_set_option(b'tile_depth', mw[3] if len(mw) > 3 else 0)
         L.urn_set_option(b'tile_il', mw[4] if len(mw) > 4 else 1)
+        L.urn_set_option(b'gconv_dbg', mw[5] if len(mw) > 5 else 0)
         if (mw[1] and (co // 16) % mw[1]) or (mw[2] and ((ci // 16) % mw[2] or mw[0] * mw[1] > 12 or (mw[0] + mw[1]) * 128 * (mw[2] * 16 + 4) > 98304)):
             continue
         t = min(run(lv, ci, co) for _ in range(3))
@@ -62,5 +65,5 @@ for lv, ci, co in shapes:
         L.urn_set_option(b'dw_blocks', 2048)
         print('L%d %3d->%3d dW us by target blocks  %s' % (lv, ci, co, ' | '.join(outs)))
         continue
-    L.urn_set_option(b'tile_rb', 0); L.urn_set_option(b'tile_cb', 0); L.urn_set_option(b'tile_kc', 0); L.urn_set_option(b'tile_il', 1)
+    L.urn_set_option(b'tile_rb', 0); L.urn_set_option(b'tile_cb', 0); L.urn_set_option(b'tile_kc', 0); L.urn_set_option(b'tile_il', 1); L.urn_set_option(b'gconv_dbg', 0)
     print('L%d %3d->%3d n=%6d fwd %s us | dW %.0f us (%.1f TF)' % (lv, ci, co, geo.n[lv], ' | '.join(out), tdw, fl / tdw / 1e6))

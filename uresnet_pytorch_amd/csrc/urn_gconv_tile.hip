@@ -45,8 +45,16 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = wave / CB, cb = wave - rb * CB;
     const int r = lane & 15, q = lane >> 4;
-    const long row_base = ((long)blockIdx.x * RB + rb) * 16;
-    const long tile_row0 = (long)blockIdx.x * RB * 16;
+    // XCD-aware row-tile assignment: workgroups are dealt to the 8 XCDs round-robin (linear id % 8), so consecutive
+    // row tiles would land on 8 different L2s and every XCD would fetch (nearly) the whole input.  Give XCD x a
+    // contiguous range of tiles instead: rows that are neighbours in space are mostly neighbours in the site order.
+    unsigned tile_x = blockIdx.x;
+    if (!(g.dbg & 64) && gridDim.y == 1) {
+        const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        tile_x = xcd * xq + (xcd < xr ? xcd : xr) + slot;
+    }
+    const long row_base = ((long)tile_x * RB + rb) * 16;
+    const long tile_row0 = (long)tile_x * RB * 16;
     const int col_base = (blockIdx.y * CB + cb) * 16;
     const int tile_col0 = blockIdx.y * CB * 16;
     const int K = g.K, cout = g.cout;
