@@ -122,6 +122,21 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     if (g.dbg & 16) m = 0u;
 
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // operands of the epilogue (residual, BatchNorm input of the backward reduce) are requested now: their round trip
+    // is hidden behind the offset loop instead of being exposed after it
+    float pre_res[4] = {0.f, 0.f, 0.f, 0.f}, pre_ex[4] = {0.f, 0.f, 0.f, 0.f};
+    float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
+    {
+        const int col = col_base + r;
+        if (g.epi == 2) { esc = g.e_scale[col]; esh = g.e_shift[col]; emu = g.e_mean[col]; eis = g.e_invstd[col]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = min(row_base + q * 4 + i, n_out - 1);
+            const long off = row * cout + col;
+            if (g.res && !STAMP) pre_res[i] = g.res[off];
+            if (g.epi == 2) pre_ex[i] = g.e_x[off];
+        }
+    }
     f32x4 ra[D][A_F4], rb_[D][B_F4];   // register ring: operands of the next D steps, in flight
     const int cin = g.cin, nch = cin / CIN;   // input-channel chunks per offset
     auto fetch = [&](int t, int ch, int gi) {
@@ -365,20 +380,18 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     double s0 = 0.0, s1 = 0.0;
     {
         const int col = col_base + r;
-        float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
-        if (g.epi == 2) { esc = g.e_scale[col]; esh = g.e_shift[col]; emu = g.e_mean[col]; eis = g.e_invstd[col]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = row_base + q * 4 + i;
             if (row >= n_out) continue;
             const long off = row * cout + col;
             float v = acc[i] + acc2[i];
-            if (g.res && !STAMP) v += g.res[off];
+            if (g.res && !STAMP) v += pre_res[i];
             if (g.epi == 1) {
                 s0 += (double)v;
                 s1 += (double)v * (double)v;
             } else if (g.epi == 2) {
-                const float xv = g.e_x[off];
+                const float xv = pre_ex[i];
                 if (!(fmaf(xv, esc, esh) > 0.f)) v = 0.f;
                 const double xh = ((double)xv - (double)emu) * (double)eis;
                 s0 += (double)v;
