@@ -190,7 +190,10 @@ __global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, c
 // S = output blocks per wave (ceil(blocks / 4)), XF = the conv input was relu(x*scale + shift).
 #define DW2_LIST 1024
 #include <type_traits>
-template <int S, int XF>
+// KT = pairs per batch: 32 for tiles of >= 3 output blocks; narrow tiles take bigger batches and split the batch's
+// pairs (the contraction dimension) over the waves, which would otherwise all compute the same block: one block
+// (16 x 16 channels): 128 pairs, 4 waves x 8 k-steps; two blocks (16 x 32, 32 x 16): 64 pairs, 2 waves per block.
+template <int S, int XF, int KT>
 __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, const float *__restrict__ xf_scale,
                                                    const float *__restrict__ xf_shift, const float *__restrict__ dy,
                                                    const int *__restrict__ tbl, long ld, long n_out, int cin,
@@ -199,8 +202,11 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
 {
     __shared__ int s_in[DW2_LIST], s_out[DW2_LIST];
     __shared__ int s_cnt[16];
-    __shared__ __attribute__((aligned(16))) float s_a[2][DW_KT][DW_MAXI * 16 + 16];
-    __shared__ __attribute__((aligned(16))) float s_b[2][DW_KT][DW_MAXN * 16 + 32];
+    // leading dimensions = 16 mod 32 floats, so that the four pair rows of a fragment read fall on different banks
+    constexpr int A_LD = KT == 32 ? DW_MAXI * 16 + 16 : (KT == 64 ? 48 : 16);
+    constexpr int B_LD = KT == 32 ? DW_MAXN * 16 + 32 : (KT == 64 ? 48 : 16);
+    __shared__ __attribute__((aligned(16))) float s_a[2][KT][A_LD];
+    __shared__ __attribute__((aligned(16))) float s_b[2][KT][B_LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
@@ -215,11 +221,16 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int blk = min(wave + 4 * s, nblk - 1);   // past the last block: recompute it (its result is not flushed)
+        // KT == 32: block b -> wave b % 4, slot b / 4; past the last block: recompute it (its result is not flushed).
+        // KT > 32 (one or two blocks, S == 1): wave -> block wave % nblk, and the batch's k-steps are split
+        const int blk = KT == 32 ? min(wave + 4 * s, nblk - 1) : wave % nblk;
         mi_[s] = blk / ni_n; ni_[s] = blk - mi_[s] * ni_n;
     }
+    constexpr int WPB = KT == 128 ? 4 : (KT == 64 ? 2 : 1);   // waves per block
+    constexpr int KSW = KT / 4 / WPB;                           // k-steps (of four pairs) per wave and batch
+    const int ks0 = KT == 32 ? 0 : (wave / (4 / WPB)) * KSW;
     // what this thread moves per batch: two 16-byte pieces of the x rows, three of the dy rows
-    const int a_tot = DW_KT * (ci_w / 4), b_tot = DW_KT * (co_w / 4);
+    const int a_tot = KT * (ci_w / 4), b_tot = KT * (co_w / 4);
     int a_rr[2], a_c4[2], b_rr[3], b_c4[3];
     f32x4 xsc[2], xsh[2];
 #pragma unroll
@@ -272,22 +283,22 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
             }
         __syncthreads();
         if (cnt == 0) continue;   // block-uniform
-        const int nbatch = (cnt + DW_KT - 1) / DW_KT;
+        const int nbatch = (cnt + KT - 1) / KT;
 
         // ---- phase B: batches of 32 pairs ----
         auto fetch_a = [&](int b, auto slot, auto jj) {
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
-            const int p = min(b * DW_KT + a_rr[j], cnt - 1);   // past the end: the last pair again (zero-filled when parked)
+            const int p = min(b * KT + a_rr[j], cnt - 1);   // past the end: the last pair again (zero-filled when parked)
             ra[u][j] = *(const f32x4 *)(x + (long)s_in[p] * cin + ci0 + 4 * a_c4[j]);
         };
         auto fetch_b = [&](int b, auto slot, auto jj) {
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
-            const int p = min(b * DW_KT + b_rr[j], cnt - 1);
+            const int p = min(b * KT + b_rr[j], cnt - 1);
             rb[u][j] = *(const f32x4 *)(dy + (long)s_out[p] * cout + co0 + 4 * b_c4[j]);
         };
         auto park_a = [&](int b, int buf, auto slot, auto jj) {
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
-            const int nb = cnt - b * DW_KT;
+            const int nb = cnt - b * KT;
             f32x4 v = ra[u][j];
             if (XF) {
 #pragma unroll
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
         };
         auto park_b = [&](int b, int buf, auto slot, auto jj) {
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
-            const int nb = cnt - b * DW_KT;
+            const int nb = cnt - b * KT;
             f32x4 v = rb[u][j];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = b_rr[j] < nb ? v[k] : 0.f;
@@ -337,7 +348,8 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
             auto group = [&](auto ss) {
                 constexpr int sl = decltype(ss)::value;
 #pragma unroll
-                for (int ks = 0; ks < DW_KT / 4; ++ks) {
+                for (int kk = 0; kk < KSW; ++kk) {
+                    const int ks = ks0 + kk;
                     const float av = s_a[buf][4 * ks + q][mi_[sl] * 16 + m];
                     const float bv = s_b[buf][4 * ks + q][ni_[sl] * 16 + m];
                     acc[sl] = MFMA16(av, bv, acc[sl]);
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
     // accumulate this block's partial into dw[o][ci][co]; C layout: col = lane&15, row = q*4+i
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        if (wave + 4 * s < nblk) {
+        if (KT > 32 || wave + 4 * s < nblk) {   // split batches: every wave holds a partial of its block
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ci = ci0 + mi_[s] * 16 + q * 4 + i, co = co0 + ni_[s] * 16 + m;
@@ -420,6 +432,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw_small(const float *__restrict_
     }
 }
 
+int g_dw_split = 1;       // split-batch variants of k_gconv_dw2 for one- and two-block tiles: 0 never, 1 automatic, 2 always (urn_set_option "dw_split")
 int g_dw_kernel = 2;      // 2 = k_gconv_dw2 (default), 1 = k_gconv_dw (urn_set_option "dw_kernel")
 int g_dw_blocks = 2048;   // target number of workgroups of the weight-gradient kernel (urn_set_option "dw_blocks")
 
@@ -461,15 +474,25 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
     const dim3 grid(chunks, K, n_ci_tiles * n_co_tiles);
     if (g_dw_kernel == 2) {
         const int ci_w = cin < DW_MAXI * 16 ? cin : DW_MAXI * 16, co_w = cout < DW_MAXN * 16 ? cout : DW_MAXN * 16;
-        const int slots = ((ci_w / 16) * (co_w / 16) + 3) / 4;   // of the widest tile
-#define URN_DW2(Sv)                                                                                                              \
-    case Sv:                                                                                                                     \
-        if (xf_scale) hipLaunchKernelGGL((k_gconv_dw2<Sv, 1>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
-                                         (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                                        \
-        else hipLaunchKernelGGL((k_gconv_dw2<Sv, 0>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,          \
-                                (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                                                 \
-        break;
-        switch (slots) { URN_DW2(1) URN_DW2(2) URN_DW2(3) URN_DW2(4) URN_DW2(5) default: break; }
+        const int nblk_max = (ci_w / 16) * (co_w / 16);   // of the widest tile
+        const int slots = (nblk_max + 3) / 4;
+        // one- and two-block tiles exist only when the whole layer is that narrow (cin, cout <= 32): then every tile
+        // of the grid has the same shape and the split-batch variants apply
+#define URN_DW2K(Sv, KTv)                                                                                                            \
+        if (xf_scale) hipLaunchKernelGGL((k_gconv_dw2<Sv, 1, KTv>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
+                                         (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                                            \
+        else hipLaunchKernelGGL((k_gconv_dw2<Sv, 0, KTv>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,          \
+                                (long)n_out, cin, cout, chunk, n_ci_tiles, dw);
+#define URN_DW2(Sv) case Sv: URN_DW2K(Sv, 32) break;
+        // The split variants keep all four matrix pipes of a CU busy: faster alone (16 x 16 at 50k rows: 29 -> 24 us;
+        // dense 128^3 model: 60.6 -> 49.6 ms per step), but in the sparse executor the weight gradients share the
+        // chip with the dX chain on the main stream and the step got 1.4 % slower -> automatic mode splits only
+        // launches large enough to own the chip.
+        const bool split = g_dw_split == 2 || (g_dw_split == 1 && n_out >= 131072);
+        if (nblk_max == 1 && split) { URN_DW2K(1, 128) }
+        else if (nblk_max == 2 && split) { URN_DW2K(1, 64) }
+        else switch (slots) { URN_DW2(1) URN_DW2(2) URN_DW2(3) URN_DW2(4) URN_DW2(5) default: break; }
+#undef URN_DW2K
 #undef URN_DW2
     } else {
         hipLaunchKernelGGL(k_gconv_dw, grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,
