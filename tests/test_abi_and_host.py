@@ -120,8 +120,57 @@ def test_trainer_checkpoint_roundtrip_dense_cpu(tmp_path):
     assert set(res.keys()) == {'segmentation', 'softmax', 'accuracy', 'loss_seg'}
     assert res['segmentation'][0].shape == (3, 16, 16) and abs(res['softmax'][0].sum(0) - 1).max() < 1e-5
     assert t.tspent['train'] > 0 and t.tspent_sum['forward'] > 0
+    # inference metrics CSV written from the same result dict (main_funcs.log_metrics)
+    from uresnet_pytorch_amd import main_funcs
+    h = SimpleNamespace(iteration=3, metrics_logger=None)
+    fl = flags(); fl.LOG_DIR = str(tmp_path)
+    main_funcs.log_metrics(h, fl, blob, res)
+    h.metrics_logger.close()
+    rows = open(str(tmp_path / 'inference_metrics-0000003.csv')).read().strip().split('\n')
+    assert rows[0].startswith('iter,id,acc,correct_softmax,nonzero_pixels,class_acc_0') and len(rows) == 3
     t.save_state(4)
     t2 = trainval(flags(str(tmp_path / 'snap-4.ckpt')))
     assert t2.initialize() == 5
     for (k1, v1), (k2, v2) in zip(t._net.state_dict().items(), t2._net.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_inference_metrics_against_brute_force():
+    """utils.compute_metrics_sparse / compute_metrics_dense against per-voxel loops."""
+    from uresnet_pytorch_amd import utils
+    rng = np.random.default_rng(0)
+    nc, S = 5, 48
+    n = 400
+    coords = rng.integers(0, S, size=(n, 3)).astype(np.float64)
+    batch = np.repeat([0., 1.], n // 2)[:, None]
+    energy = rng.uniform(0.1, 3.0, size=(n, 1))
+    data = np.concatenate([coords, batch, energy], 1)
+    label = rng.integers(0, nc, size=(n, 1)).astype(np.float64)
+    soft = rng.dirichlet(np.ones(nc), size=n)
+    res, _ = utils.compute_metrics_sparse([data], [label], [soft], None, N=S)
+    assert len(res['acc']) == 2 and res['id'] == [0.0, 1.0]
+    for e in range(2):
+        sel = np.where(batch[:, 0] == e)[0]
+        conf = np.zeros((nc, nc), np.int32); econf = np.zeros((nc, nc), np.float64); hit = 0; ll = 0.0
+        for i in sel:
+            p = int(np.argmax(soft[i])); t = int(label[i, 0])
+            conf[t, p] += 1; econf[t, p] += energy[i, 0]; hit += p == t; ll -= np.log(soft[i, t])
+        assert abs(res['acc'][e] - hit / len(sel)) < 1e-12 and abs(res['loss_seg'][e] - ll / len(sel)) < 1e-9
+        assert np.array_equal(res['confusion_matrix'][e], conf) and np.allclose(res['energy_confusion_matrix'][e], econf, rtol=1e-5)
+        assert res['nonzero_pixels'][e] == len(sel) and res['misclassified_pixels'][e].shape == (len(sel) - hit, 3 + 5)
+        assert np.allclose(res['class_acc'][e], np.diag(conf) / conf.sum(1)) and res['distances'][e].sum() <= len(sel)
+        assert np.array_equal(res['class_pixel'][e], conf.sum(1))
+    # dense: 2-D image, background = last class at empty pixels
+    H = 24
+    img = np.zeros((1, H, H)); lab = np.full((1, H, H), nc - 1.0)
+    m = rng.uniform(size=(H, H)) < 0.3
+    img[0][m] = rng.uniform(0.1, 1.0, size=int(m.sum())); lab[0][m] = rng.integers(0, nc - 1, size=int(m.sum()))
+    sm = rng.dirichlet(np.ones(nc), size=H * H).T.reshape(nc, H, H)
+    r = utils.compute_metrics_dense([img], [lab], [sm], None)
+    pred = sm.argmax(0)
+    assert abs(r['acc'][0] - (pred[m] == lab[0][m]).mean()) < 1e-12 and r['nonzero_pixels'][0] == int(m.sum())
+    conf = np.zeros((nc - 1, nc - 1), np.int32)
+    for y, x in zip(*np.where(m)):
+        if pred[y, x] < nc - 1:
+            conf[int(lab[0, y, x]), pred[y, x]] += 1
+    assert np.array_equal(r['confusion_matrix'][0], conf) and r['confusion_matrix'][0].shape == (nc - 1, nc - 1)

@@ -1,6 +1,7 @@
 """train / inference / iotest drivers with the reference's call contract into the trainer
-(reference uresnet/main_funcs.py:17-259).  Host orchestration only; the full-inference
-physics metrics (reference :262-466) are out of scope."""
+(reference uresnet/main_funcs.py:17-259).  Host orchestration only; of the full-inference physics
+metrics (reference :262-466) the per-event accuracy / per-class / confusion part is available
+(utils.compute_metrics_*, written by inference_loop to a CSV), the Michel-electron analysis is out of scope."""
 import datetime
 import os
 import sys
@@ -143,6 +144,30 @@ def train_loop(flags, handlers):
     handlers.data_io.finalize()
 
 
+def log_metrics(handlers, flags, data_blob, res):
+    """Per-event inference metrics (utils.compute_metrics_*; the non-Michel part of what the reference's
+    full_inference_loop records, main_funcs.py:262-466) into <LOG_DIR>/inference_metrics-*.csv."""
+    if not flags.LOG_DIR or 'label' not in data_blob or 'softmax' not in res:
+        return
+    if getattr(handlers, 'metrics_logger', None) is None:
+        handlers.metrics_logger = utils.CSVData('%s/inference_metrics-%07d.csv' % (flags.LOG_DIR, handlers.iteration))
+    lg = handlers.metrics_logger
+    data_v = [d for sub in data_blob['data'] for d in sub]
+    label_v = [d for sub in data_blob['label'] for d in sub]
+    soft_v = list(res['softmax'])
+    if 'sparse' in flags.MODEL_NAME:
+        m, _ = utils.compute_metrics_sparse(data_v, label_v, soft_v, None, N=flags.SPATIAL_SIZE)
+    else:
+        m = utils.compute_metrics_dense(data_v, label_v, soft_v, None)   # one (C, [D,] H, W) array per event
+    for e in range(len(m['acc'])):
+        lg.record(('iter', 'id', 'acc', 'correct_softmax', 'nonzero_pixels'),
+                  (handlers.iteration, m['id'][e], m['acc'][e], m['correct_softmax'][e], m['nonzero_pixels'][e]))
+        for c, a in enumerate(m['class_acc'][e]):
+            lg.record(('class_acc_%d' % c, 'class_pixel_%d' % c), (float(np.nan_to_num(a)), float(m['class_pixel'][e][c])))
+        lg.write()
+    lg.flush()
+
+
 def inference_loop(flags, handlers):
     data_key, label_key, weight_key = get_keys(flags)
     tsum = 0.
@@ -152,6 +177,7 @@ def inference_loop(flags, handlers):
         tstart_iteration = time.time()
         data_blob = get_data_minibatched(handlers, flags, data_key, label_key, weight_key)
         res = handlers.trainer.forward(data_blob, epoch=float(epoch), batch_size=flags.BATCH_SIZE)
+        log_metrics(handlers, flags, data_blob, res)
         tspent_iteration = time.time() - tstart_iteration
         tsum += tspent_iteration
         log(handlers, tstamp_iteration, tspent_iteration, tsum, res, flags, epoch)
