@@ -6,6 +6,8 @@ by uresnet_pytorch_amd.scn, i.e. hand-written gfx950 kernels behind the C ABI.
 """
 import torch
 
+from ..utils import DeferredFloat
+
 from .. import scn
 from .. import sparse_ops as so
 from ..trunk import TrunkExecutor
@@ -102,4 +104,6 @@ class SegmentationLoss(torch.nn.modules.loss._Loss):
             correct = (torch.argmax(segmentation[i], dim=-1) == event_label).to(loss_seg.dtype)
             acc = torch.zeros(nev, device=loss_seg.device, dtype=loss_seg.dtype).index_add_(0, inv, correct)
             total_acc = total_acc + (acc / cnt).sum()
+        if torch.is_tensor(total_acc) and total_acc.is_cuda:
+            return total_loss, DeferredFloat(total_acc)   # a float when used; no host sync between forward and backward
         return total_loss, float(total_acc)

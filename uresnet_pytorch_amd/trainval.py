@@ -57,14 +57,17 @@ class trainval(object):
     def train_step(self, data_blob, epoch=None, batch_size=1):
         tstart = time.time()
         self._loss = []
-        res_combined = self.forward(data_blob, epoch=epoch, batch_size=batch_size)
+        # the host copies of logits/softmax/loss/accuracy (reference :126-131) are made AFTER the backward pass and
+        # the optimizer step have been enqueued: same dict, no host stall between forward and backward
+        res_combined = self.forward(data_blob, epoch=epoch, batch_size=batch_size, _defer=True)
         self.backward()
+        res_combined = self._finish(res_combined, batch_size)
         self.tspent['train'] = time.time() - tstart
         self.tspent_sum['train'] += self.tspent['train']
         return res_combined
 
     # -- reference trainval.py:53-73
-    def forward(self, data_blob, epoch=None, batch_size=1):
+    def forward(self, data_blob, epoch=None, batch_size=1, _defer=False):
         res_combined = {}
         for idx in range(len(data_blob['data'])):
             blob = {}
@@ -76,8 +79,16 @@ class trainval(object):
                     res_combined[key] = res[key]
                 else:
                     res_combined[key].extend(res[key])
-        acc = float(np.array(res_combined['accuracy']).sum())
-        loss = float(np.array(res_combined['loss_seg']).sum())
+        return res_combined if _defer else self._finish(res_combined, batch_size)
+
+    def _finish(self, res_combined, batch_size):
+        """device results -> the reference's host dict: numpy logits/softmax per entry, loss and accuracy summed
+        over entries (and ranks) and divided by batch_size (reference :71-72, :126-131)"""
+        seg = res_combined['segmentation']
+        res_combined['softmax'] = [self._softmax(s).detach().cpu().numpy() for s in seg]
+        res_combined['segmentation'] = [s.detach().cpu().numpy() for s in seg]
+        acc = float(sum(float(a) for a in res_combined['accuracy']))
+        loss = float(sum(l if isinstance(l, float) else l.item() for l in res_combined['loss_seg']))
         acc, loss = parallel.all_reduce_scalars([acc, loss], self._device)
         res_combined['accuracy'] = acc / batch_size
         res_combined['loss_seg'] = loss / batch_size
@@ -113,11 +124,10 @@ class trainval(object):
                 loss_seg, acc = self._criterion(segmentation, data, label, weight)
                 if self._flags.TRAIN:
                     self._loss.append(loss_seg)
-            res = {
-                'segmentation': [s.detach().cpu().numpy() for s in segmentation],
-                'softmax': [self._softmax(s).detach().cpu().numpy() for s in segmentation],
+            res = {   # still on the device: _finish() makes the host copies
+                'segmentation': [s.detach() for s in segmentation],
                 'accuracy': [acc],
-                'loss_seg': [loss_seg.item() if not isinstance(loss_seg, float) else loss_seg]
+                'loss_seg': [loss_seg if isinstance(loss_seg, float) else loss_seg.detach()]
             }
             self.tspent['forward'] = time.time() - tstart
             self.tspent_sum['forward'] += self.tspent['forward']

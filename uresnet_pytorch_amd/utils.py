@@ -28,6 +28,44 @@ class CSVData:
             self._fout.close()
 
 
+class DeferredFloat:
+    """A python-float stand-in for a scalar that still lives on the device: the value is copied to the host (one
+    synchronisation) the first time it is USED as a number.  SegmentationLoss returns the accuracy this way, so a
+    training step that does not look at it (or looks at it after the backward pass has been enqueued) does not stall
+    the host between forward and backward (lazy D2H)."""
+    __slots__ = ('_t', '_v')
+
+    def __init__(self, tensor):
+        self._t, self._v = tensor, None
+
+    def __float__(self):
+        if self._v is None:
+            self._v = float(self._t)
+            self._t = None
+        return self._v
+
+    def __repr__(self): return repr(float(self))
+    def __format__(self, spec): return format(float(self), spec)
+    def __bool__(self): return bool(float(self))
+    def __int__(self): return int(float(self))
+    def __neg__(self): return -float(self)
+    def __abs__(self): return abs(float(self))
+    def __add__(self, o): return float(self) + o
+    def __radd__(self, o): return o + float(self)
+    def __sub__(self, o): return float(self) - o
+    def __rsub__(self, o): return o - float(self)
+    def __mul__(self, o): return float(self) * o
+    def __rmul__(self, o): return o * float(self)
+    def __truediv__(self, o): return float(self) / o
+    def __rtruediv__(self, o): return o / float(self)
+    def __eq__(self, o): return float(self) == o
+    def __lt__(self, o): return float(self) < o
+    def __le__(self, o): return float(self) <= o
+    def __gt__(self, o): return float(self) > o
+    def __ge__(self, o): return float(self) >= o
+    __hash__ = None
+
+
 def round_decimals(val, digits):
     factor = float(10 ** digits)
     return int(val * factor + 0.5) / factor
