@@ -77,6 +77,17 @@ int urn_level_down(const int32_t *fine_coords, const int32_t *n_fine, int64_t n_
                    int64_t hcap, void *scratch, int64_t scratch_bytes, int32_t *coarse_coords,
                    int32_t *parent, int32_t *off, int32_t *n_coarse, void *stream);
 
+/* urn_level_down and urn_down_tables in one pass (chd/up as below, pre-filled with -1; both NULL = level_down only) */
+int urn_level_down_tables(const int32_t *fine_coords, const int32_t *n_fine, int64_t n_cap, void *hash,
+                          int64_t hcap, void *scratch, int64_t scratch_bytes, int32_t *coarse_coords,
+                          int32_t *parent, int32_t *off, int32_t *n_coarse, int32_t *chd, int64_t ld_c,
+                          int32_t *up, int64_t ld_f, void *stream);
+/* urn_rulebook_subm for up to 8 levels of one geometry in a single launch: arrays of num_levels host pointers /
+ * values (site coordinates, device counts, spatial sizes, hashes of capacity hcap, tables [27][ld]) */
+int urn_rulebook_subm_multi(int num_levels, const int32_t *const *site_coords, const int32_t *const *n_dev,
+                            int64_t n_cap, const int *spatial, const void *const *hash, int64_t hcap,
+                            int32_t *const *nbr, int64_t ld, void *stream);
+
 /* Gather tables of the strided pair: chd[8][ld_c] (coarse j <- fine child at offset o) and
  * up[8][ld_f] (fine i <- parent[i] at o == off[i]).  Both must be pre-filled with -1
  * by the caller (urn_fill_i32). */

@@ -139,47 +139,32 @@ __global__ void k_flag_count(const int *n_dev, long n_cap, HashView h, const int
     if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 
-// U3: exclusive scan of the block sums by one 1024-thread block
-__global__ void k_scan_blocks(int *blocksum, int nblk, int *n_unique)
-{
-    __shared__ int s[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nblk; b0 += 1024) {
-        int i = b0 + threadIdx.x;
-        int v = i < nblk ? blocksum[i] : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            int t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        int incl = s[threadIdx.x];
-        int c = carry;
-        if (i < nblk) blocksum[i] = c + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *n_unique = carry;
-}
-
 // U4: number the first-occurrence rows in row order, write site coords, publish slot->site
+// (U3, the exclusive scan of the per-block counts, happens here: every block adds up the counts of the blocks before
+// it -- a few hundred integers -- instead of a separate one-block scan launch; the last block publishes the total)
 __global__ void k_assign(const int *__restrict__ coords, const int *n_dev, long n_cap, int shift,
                          HashView h, const int *__restrict__ rowslot,
-                         const int *__restrict__ blocksum, int *__restrict__ site_coords)
+                         const int *__restrict__ blocksum, int *__restrict__ site_coords, int *__restrict__ n_unique)
 {
+    __shared__ int s_part[UB / 64];
     long n = n_dev ? (long)*n_dev : n_cap;
     long i = (long)blockIdx.x * UB + threadIdx.x;
     int slot = (i < n) ? rowslot[i] : 0;
     bool f = (i < n) && (h.first[slot] == (int)i);
+    int mine = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += UB) mine += blocksum[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < UB / 64; ++k) base += s_part[k];
     int tot;
     int pre = block_prefix(f, &tot);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_unique = base + tot;
     if (f) {
-        int s = blocksum[blockIdx.x] + pre;
+        int s = base + pre;
         int4 c = ((const int4 *)coords)[i];
         c.x >>= shift; c.y >>= shift; c.z >>= shift;
         ((int4 *)site_coords)[s] = c;
@@ -199,14 +184,20 @@ __global__ void k_row2site(const int *n_dev, long n_cap, HashView h, const int *
 // U5b: fine site -> coarse parent and 2^3 offset
 __global__ void k_parent_off(const int *__restrict__ coords, const int *n_dev, long n_cap, HashView h,
                              const int *__restrict__ rowslot, int *__restrict__ parent,
-                             int *__restrict__ off)
+                             int *__restrict__ off, int *__restrict__ chd, long ld_c, int *__restrict__ up, long ld_f)
 {
     long n = n_dev ? (long)*n_dev : n_cap;
     long i = (long)blockIdx.x * UB + threadIdx.x;
     if (i >= n) return;
     int4 c = ((const int4 *)coords)[i];
-    parent[i] = h.site[rowslot[i]];
-    off[i] = ((c.x & 1) * 2 + (c.y & 1)) * 2 + (c.z & 1);
+    const int p = h.site[rowslot[i]];
+    const int o = ((c.x & 1) * 2 + (c.y & 1)) * 2 + (c.z & 1);
+    parent[i] = p;
+    off[i] = o;
+    if (chd) {   // the gather tables of the strided pair in the same pass (urn_level_down_tables)
+        chd[(long)o * ld_c + p] = (int)i;
+        up[(long)o * ld_f + i] = p;
+    }
 }
 
 static int run_unique(const int32_t *coords, const int *n_dev, int64_t n_cap, int shift, void *hash,
@@ -232,9 +223,8 @@ static int run_unique(const int32_t *coords, const int *n_dev, int64_t n_cap, in
     }
     hipLaunchKernelGGL(k_insert, dim3(nblk), dim3(UB), 0, st, coords, n_dev, (long)n_cap, shift, h, rowslot);
     hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(UB), 0, st, n_dev, (long)n_cap, h, rowslot, blocksum);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blocksum, nblk, n_unique);
     hipLaunchKernelGGL(k_assign, dim3(nblk), dim3(UB), 0, st, coords, n_dev, (long)n_cap, shift, h, rowslot,
-                       blocksum, site_coords);
+                       blocksum, site_coords, n_unique);
     return URN_OK;
 }
 
@@ -265,8 +255,18 @@ extern "C" int urn_level_down(const int32_t *fine_coords, const int32_t *n_fine,
                               int32_t *coarse_coords, int32_t *parent, int32_t *off, int32_t *n_coarse,
                               void *stream)
 {
+    return urn_level_down_tables(fine_coords, n_fine, n_cap, hash, hcap, scratch, scratch_bytes, coarse_coords, parent,
+                                 off, n_coarse, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int urn_level_down_tables(const int32_t *fine_coords, const int32_t *n_fine, int64_t n_cap, void *hash,
+                                     int64_t hcap, void *scratch, int64_t scratch_bytes, int32_t *coarse_coords,
+                                     int32_t *parent, int32_t *off, int32_t *n_coarse, int32_t *chd, int64_t ld_c,
+                                     int32_t *up, int64_t ld_f, void *stream)
+{
     URN_CHECK_ARG(n_cap >= 0 && hash && scratch && n_coarse, "null pointer");
     URN_CHECK_ARG(n_cap == 0 || (fine_coords && coarse_coords && parent && off), "null pointer");
+    URN_CHECK_ARG((chd == nullptr) == (up == nullptr), "chd and up go together");
     hipStream_t st = (hipStream_t)stream;
     int *rowslot;
     int rc = run_unique(fine_coords, n_fine, n_cap, 1, hash, hcap, scratch, scratch_bytes, coarse_coords,
@@ -275,7 +275,7 @@ extern "C" int urn_level_down(const int32_t *fine_coords, const int32_t *n_fine,
     if (n_cap > 0) {
         HashView h = hash_view(hash, hcap);
         hipLaunchKernelGGL(k_parent_off, dim3((int)n_blocks(n_cap)), dim3(UB), 0, st, fine_coords, n_fine,
-                           (long)n_cap, h, rowslot, parent, off);
+                           (long)n_cap, h, rowslot, parent, off, chd, (long)ld_c, up, (long)ld_f);
     }
     URN_LAUNCH_CHECK();
     return URN_OK;
@@ -332,6 +332,61 @@ __global__ void k_rulebook_subm(const int *__restrict__ coords, const int *n_dev
         unsigned long long b = __ballot(v >= 0);
         if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_rules, __popcll(b));
     }
+}
+
+// all levels of one geometry in a single launch: grid (row blocks, 27, levels)
+#define URN_RB_MAX_LEVELS 8
+struct RBLevels {
+    const int *coords[URN_RB_MAX_LEVELS];
+    const int *n_dev[URN_RB_MAX_LEVELS];
+    int *nbr[URN_RB_MAX_LEVELS];
+    HashView h[URN_RB_MAX_LEVELS];
+    int spatial[URN_RB_MAX_LEVELS];
+};
+
+__global__ void k_rulebook_subm_multi(RBLevels lv, long n_cap, long ld)
+{
+    const int l = blockIdx.z;
+    const long n = (long)*lv.n_dev[l];
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int o = blockIdx.y;
+    const int dx = o / 9 - 1, dy = (o / 3) % 3 - 1, dz = o % 3 - 1;
+    const HashView h = lv.h[l];
+    const int spatial = lv.spatial[l];
+    int v = -1;
+    const int4 c = ((const int4 *)lv.coords[l])[j];
+    const int x = c.x + dx, y = c.y + dy, z = c.z + dz;
+    if (x >= 0 && y >= 0 && z >= 0 && x < spatial && y < spatial && z < spatial) {
+        const unsigned long long key = urn_key(x, y, z, c.w);
+        unsigned long long s = urn_mix(key) & h.mask;
+        for (;;) {
+            const unsigned long long k = h.keys[s];
+            if (k == key) { v = h.site[s]; break; }
+            if (k == URN_EMPTY_KEY) break;
+            s = (s + 1) & h.mask;
+        }
+    }
+    lv.nbr[l][(long)o * ld + j] = v;
+}
+
+extern "C" int urn_rulebook_subm_multi(int num_levels, const int32_t *const *site_coords, const int32_t *const *n_dev,
+                                       int64_t n_cap, const int *spatial, const void *const *hash, int64_t hcap,
+                                       int32_t *const *nbr, int64_t ld, void *stream)
+{
+    if (n_cap <= 0 || num_levels <= 0) return URN_OK;
+    URN_CHECK_ARG(num_levels <= URN_RB_MAX_LEVELS && site_coords && n_dev && spatial && hash && nbr, "bad argument");
+    URN_CHECK_ARG(ld >= n_cap, "ld < n_cap");
+    RBLevels lv;
+    for (int l = 0; l < num_levels; ++l) {
+        URN_CHECK_ARG(site_coords[l] && n_dev[l] && hash[l] && nbr[l], "null pointer");
+        lv.coords[l] = site_coords[l]; lv.n_dev[l] = n_dev[l]; lv.nbr[l] = nbr[l];
+        lv.h[l] = hash_view((void *)hash[l], hcap); lv.spatial[l] = spatial[l];
+    }
+    hipLaunchKernelGGL(k_rulebook_subm_multi, dim3(urn_cdiv(n_cap, 256), 27, num_levels), dim3(256), 0, (hipStream_t)stream,
+                       lv, (long)n_cap, (long)ld);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
 }
 
 extern "C" int urn_rulebook_subm(const int32_t *site_coords, const int32_t *n_dev, int64_t n_cap, int spatial,

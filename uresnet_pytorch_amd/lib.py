@@ -53,6 +53,10 @@ SIGNATURES = {
                                   c_void_p]),
     'urn_level_down': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
+    'urn_level_down_tables': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
+    'urn_rulebook_subm_multi': (c_int, [c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
+                                        c_void_p]),
     'urn_down_tables': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
     'urn_fill_i32': (c_int, [c_void_p, c_i64, ctypes.c_int32, c_void_p]),
     'urn_gconv_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_int, c_int, c_void_p,

@@ -1,6 +1,8 @@
 """Host side of the sparse path: geometry (integer phase) and autograd Functions that
 call the HIP kernels through the C ABI.  PyTorch only owns memory and the stream.
 """
+import ctypes
+
 import torch
 
 from . import lib as _l
@@ -50,6 +52,7 @@ class SparseGeometry:
         self.ld = cap                      # leading dimension of every gather table
         self.nbr, self.parent, self.off, self.chd, self.up = [], [], [], [], []
         sp = self.spatial
+        spatials = []
         # strided tables are filled with -1 by one launch
         if self.num_levels > 1:
             self._strided = torch.empty((self.num_levels - 1, 2, 8, cap), dtype=torch.int32, device=dev)
@@ -61,19 +64,22 @@ class SparseGeometry:
                 cc = torch.empty((cap, 4), dtype=torch.int32, device=dev)
                 parent = torch.empty(cap, dtype=torch.int32, device=dev)
                 off = torch.empty(cap, dtype=torch.int32, device=dev)
-                _l.check(L.urn_level_down(self.coords[l].data_ptr(), n_dev, cap, self._hptr[l + 1], hcap,
-                                          scratch.data_ptr(), sbytes, cc.data_ptr(), parent.data_ptr(),
-                                          off.data_ptr(), cptr + 4 * (l + 1), st), 'level_down')
                 chd, up = self._strided[l, 0], self._strided[l, 1]
-                _l.check(L.urn_down_tables(parent.data_ptr(), off.data_ptr(), n_dev, cap, chd.data_ptr(), cap,
-                                           up.data_ptr(), cap, st), 'down_tables')
+                _l.check(L.urn_level_down_tables(self.coords[l].data_ptr(), n_dev, cap, self._hptr[l + 1], hcap,
+                                                 scratch.data_ptr(), sbytes, cc.data_ptr(), parent.data_ptr(),
+                                                 off.data_ptr(), cptr + 4 * (l + 1), chd.data_ptr(), cap,
+                                                 up.data_ptr(), cap, st), 'level_down_tables')
                 self.coords.append(cc); self.parent.append(parent); self.off.append(off)
                 self.chd.append(chd); self.up.append(up)
-            nbr = self._nbr_all[l]
-            _l.check(L.urn_rulebook_subm(self.coords[l].data_ptr(), n_dev, cap, sp, self._hptr[l], hcap,
-                                         nbr.data_ptr(), cap, None, st), 'rulebook_subm')
-            self.nbr.append(nbr)
+            self.nbr.append(self._nbr_all[l])
+            spatials.append(sp)
             sp = (sp + 1) // 2
+        # the 27-offset tables of every level in one launch
+        nl = self.num_levels
+        PA, IA = ctypes.c_void_p * nl, ctypes.c_int * nl
+        _l.check(L.urn_rulebook_subm_multi(nl, PA(*[c.data_ptr() for c in self.coords]), PA(*[cptr + 4 * l for l in range(nl)]),
+                                           cap, IA(*spatials), PA(*self._hptr), hcap, PA(*[t.data_ptr() for t in self.nbr]),
+                                           cap, st), 'rulebook_subm_multi')
         self._scratch = scratch
         host = self.counts.cpu().tolist()       # the one sync of the integer phase
         self.n = host[:self.num_levels]
