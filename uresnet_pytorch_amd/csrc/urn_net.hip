@@ -647,7 +647,8 @@ static void run_forward(urn_net *net, const float *site_feats)
     if (net->fused) {
         net->fwd_stamp++;
         net->sync_word = (uint32_t *)net->arena.alloc_bytes(256);
-        if (net->live()) net->check(hipMemsetAsync(net->sync_word, 0, 256, net->st) == hipSuccess ? URN_OK : URN_EHIP);
+        // (the ticket word is only used by the in-kernel finalize of the slab-statistics mode)
+        if (net->live() && !net->sums_mode()) net->check(hipMemsetAsync(net->sync_word, 0, 256, net->st) == hipSuccess ? URN_OK : URN_EHIP);
         if (net->sums_mode()) net->sums_begin();
         Act f;
         f.x = const_cast<float *>(site_feats); f.n = n0; f.c = 1;

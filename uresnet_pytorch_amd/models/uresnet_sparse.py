@@ -46,7 +46,7 @@ class UResNet(torch.nn.Module):
         inp = self.sparseModel[0]
         c = coords.to(torch.int32) if coords.dtype != torch.int32 else coords
         geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels)
-        ex.flatten(c.device)
+        ex.flatten(c.device, tail=(self.linear.weight, self.linear.bias))
         return ex.forward(geo, so.input_features(geo, features), True)
 
     def forward(self, point_cloud):

@@ -94,22 +94,34 @@ class TrunkExecutor:
             pass
 
     # -- flat storage ------------------------------------------------------------------
-    def _aliased(self, dev):
+    def _aliased(self, dev, tail=()):
         if self.flat is None or self.flat.device != dev:
             return False
         base = self.flat.data_ptr()
+        o = self.n_params
+        for p in tail:
+            if p.data_ptr() != base + 4 * o:
+                return False
+            o += p.numel()
         return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
 
-    def flatten(self, dev):
-        """(Re)point parameters and BN buffers at the flat tensors; values are preserved."""
+    def flatten(self, dev, tail=()):
+        """(Re)point parameters and BN buffers at the flat tensors; values are preserved.  `tail`: further
+        parameters of the model (the Linear head) homed right behind the trunk's, so that the whole model is ONE
+        contiguous segment for the optimizer."""
         if self.handle is None:
             self._create()
-        if self._aliased(dev):
+        if self._aliased(dev, tail):
             return
-        flat = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+        flat = torch.empty(self.n_params + sum(p.numel() for p in tail), dtype=torch.float32, device=dev)
         for p, o in zip(self.params, self.offsets):
             flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
             p.data = flat[o:o + p.numel()].view(p.shape)
+        o = self.n_params
+        for p in tail:
+            flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
         running = torch.empty(max(self.n_running, 1), dtype=torch.float32, device=dev)
         o = 0
         for b in self.bns:
