@@ -45,9 +45,13 @@ class UResNet(torch.nn.Module):
         ex = self._executor
         inp = self.sparseModel[0]
         c = coords.to(torch.int32) if coords.dtype != torch.int32 else coords
-        geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels)
+        # everything that does not need the level counts goes BEFORE their read-back (geo.sync() inside forward):
+        # host time after that synchronisation is exposed in the step, host time before it is not
         ex.flatten(c.device, tail=(self.linear.weight, self.linear.bias))
-        return ex.forward(geo, so.input_features(geo, features), True)
+        geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels, defer_sync=True)
+        feats = so.input_features(geo, features)
+        ex.prepare(geo, True)
+        return ex.forward(geo, feats, True)
 
     def forward(self, point_cloud):
         """point_cloud: (N, d+2) rows [x, y, z, batch_id, value]; returns [ (N, NUM_CLASS) ]."""

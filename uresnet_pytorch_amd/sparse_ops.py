@@ -18,7 +18,10 @@ class SparseGeometry:
     (uresnet/models/uresnet_sparse.py:20-22).
     """
 
-    def __init__(self, coords, spatial_size, num_levels=1):
+    def __init__(self, coords, spatial_size, num_levels=1, defer_sync=False):
+        """defer_sync=True: everything is enqueued but the level counts are not read back yet -- the caller does the
+        rest of its host-side preparation (measured: host time after this synchronisation is exposed one to one in
+        the step, host time before it is hidden behind the previous step's kernels) and then calls sync()."""
         _l.require_gpu(coords)
         L = _l.load()
         assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
@@ -81,9 +84,16 @@ class SparseGeometry:
                                            cap, IA(*spatials), PA(*self._hptr), hcap, PA(*[t.data_ptr() for t in self.nbr]),
                                            cap, st), 'rulebook_subm_multi')
         self._scratch = scratch
-        host = self.counts.cpu().tolist()       # the one sync of the integer phase
-        self.n = host[:self.num_levels]
         self._rules = None
+        self.n = None
+        if not defer_sync:
+            self.sync()
+
+    def sync(self):
+        """the one host synchronisation of the integer phase: per-level site counts"""
+        if self.n is None:
+            self.n = self.counts.cpu().tolist()[:self.num_levels]
+        return self
 
     @property
     def rules(self):
@@ -101,14 +111,18 @@ class SparseGeometry:
 
 
 def input_features(geo, feats):
-    """InputLayer mode 3: site features = sum of the rows that share a site."""
+    """InputLayer mode 3: site features = sum of the rows that share a site.  With an unsynchronised geometry the
+    site count stays on the device: the result then has geo.cap rows of which the first n[0] are sites."""
     L = _l.load()
     feats = feats.contiguous().float()
     nf = feats.shape[1]
-    n0 = geo.n[0]
+    if geo.n is None:
+        n0, n_dev = geo.cap, geo.counts.data_ptr()
+    else:
+        n0, n_dev = geo.n[0], None
     out = torch.empty((n0, nf), dtype=torch.float32, device=feats.device)
     acc = torch.empty(max(n0 * nf, 1), dtype=torch.float64, device=feats.device)
-    _l.check(L.urn_input_features(feats.data_ptr(), geo.row2site.data_ptr(), geo.n_rows, nf, None, n0,
+    _l.check(L.urn_input_features(feats.data_ptr(), geo.row2site.data_ptr(), geo.n_rows, nf, n_dev, n0,
                                   acc.data_ptr(), out.data_ptr(), _l.stream()), 'input_features')
     return out
 

@@ -45,6 +45,8 @@ class TrunkExecutor:
         self.flat = None
         self.running = None
         self.flat_grad = None
+        self._ws_coef = {}
+        self._prep = None
 
     # -- handle ------------------------------------------------------------------------
     def _new_handle(self):
@@ -103,7 +105,9 @@ class TrunkExecutor:
             if p.data_ptr() != base + 4 * o:
                 return False
             o += p.numel()
-        return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+        # re-homing moves every parameter at once: three probes are enough (190 data_ptr() calls per step otherwise)
+        probe = (0, len(self.params) // 2, len(self.params) - 1)
+        return all(self.params[i].data_ptr() == base + 4 * self.offsets[i] for i in probe)
 
     def flatten(self, dev, tail=()):
         """(Re)point parameters and BN buffers at the flat tensors; values are preserved.  `tail`: further
@@ -154,16 +158,47 @@ class TrunkExecutor:
             p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
         return self.flat_grad.data_ptr(), self.flat_grad
 
+    def _ws_model(self, slot, num_levels, with_backward):
+        """The workspace need is linear in the level sizes and the row count (every allocation is rows x channels,
+        rounded up to 256 B): one dry run per unit vector, cached, replaces a dry run of the whole graph per step --
+        that call sat between the level-count synchronisation and the first kernel of the forward pass."""
+        key = (num_levels, int(with_backward))
+        if key not in self._ws_coef:
+            L = _l.load()
+            U = 1 << 16
+
+            def need(n, rows):
+                v = L.urn_net_workspace_bytes(slot.handle, num_levels, (ctypes.c_int64 * num_levels)(*n), rows, int(with_backward))
+                if v < 0:
+                    raise RuntimeError('urn_net_workspace_bytes failed')
+                return v
+            zero = [0] * num_levels
+            f0 = need(zero, 0)
+            coef = [(need([U if k == l else 0 for k in range(num_levels)], 0) - f0) / U for l in range(num_levels)]
+            crow = (need(zero, U) - f0) / U
+            self._ws_coef[key] = (f0, coef, crow)
+        return self._ws_coef[key]
+
     def workspace(self, slot, geo, with_backward):
-        L = _l.load()
-        n = (ctypes.c_int64 * geo.num_levels)(*geo.n)
-        need = L.urn_net_workspace_bytes(slot.handle, geo.num_levels, n, geo.n_rows, int(with_backward))
-        if need < 0:
-            raise RuntimeError('urn_net_workspace_bytes failed')
+        f0, coef, crow = self._ws_model(slot, geo.num_levels, with_backward)
+        need = int((f0 + sum(c * n for c, n in zip(coef, geo.n)) + crow * geo.n_rows) * 1.01) + (1 << 20)
         if slot.ws is None or slot.ws_bytes < need or slot.ws.device != geo.device:
             slot.ws_bytes = int(need * 1.25)
             slot.ws = torch.empty(slot.ws_bytes, dtype=torch.uint8, device=geo.device)
         return slot.ws, slot.ws_bytes
+
+    def prepare(self, geo, training):
+        """Host-side preparation of forward() that does not need the level counts; call it BEFORE geo.sync()."""
+        Lv = geo.num_levels
+        slot = self.acquire()
+        need_bwd = bool(training and torch.is_grad_enabled())
+        self._ws_model(slot, Lv, need_bwd)
+        self._prep = dict(
+            geo=geo, slot=slot, need_bwd=need_bwd,
+            nbr=(ctypes.c_void_p * Lv)(*[t.data_ptr() for t in geo.nbr]),
+            chd=(ctypes.c_void_p * Lv)(*([t.data_ptr() for t in geo.chd] + [None])),
+            up=(ctypes.c_void_p * Lv)(*([t.data_ptr() for t in geo.up] + [None])),
+            out=torch.empty((geo.n_rows, self.cfg[0]), dtype=torch.float32, device=geo.device))
 
     def forward(self, geo, feats, training):
         """site features -> (n_rows, m) rows in input order.  Recorded for backward when training."""
@@ -181,14 +216,15 @@ class _TrunkFunction(torch.autograd.Function):
         L = _l.load()
         Lv = geo.num_levels
         training = True
-        slot = ex.acquire()
+        prep = ex._prep if (ex._prep is not None and ex._prep['geo'] is geo and ex._prep['need_bwd'] == need_bwd) else None
+        ex._prep = None
+        if prep is None:
+            ex.prepare(geo, need_bwd)
+            prep, ex._prep = ex._prep, None
+        slot, nbr, chd, up, out = prep['slot'], prep['nbr'], prep['chd'], prep['up'], prep['out']
+        geo.sync()
         ws, ws_bytes = ex.workspace(slot, geo, need_bwd)
         n = (ctypes.c_int64 * Lv)(*geo.n)
-        nbr = (ctypes.c_void_p * Lv)(*[t.data_ptr() for t in geo.nbr])
-        chd = (ctypes.c_void_p * Lv)(*([t.data_ptr() for t in geo.chd] + [None]))
-        up = (ctypes.c_void_p * Lv)(*([t.data_ptr() for t in geo.up] + [None]))
-        m = ex.cfg[0]
-        out = torch.empty((geo.n_rows, m), dtype=torch.float32, device=feats.device)
         feats = feats.contiguous()
         _l.check(L.urn_net_forward(slot.handle, Lv, geo.ld, n, nbr, chd, up, geo.row2site.data_ptr(), geo.n_rows,
                                    ex.flat.data_ptr(), ex.running.data_ptr(), feats.data_ptr(), ws.data_ptr(),
