@@ -17,7 +17,7 @@ crit = SparseSegmentationLoss(flags)
 variants = {}
 from uresnet_pytorch_amd import lib as _lib
 L = _lib.load()
-for name, fl in (('default', 0), ('slab stats', 4)):
+for name, fl in (('default', 0),):
     torch.manual_seed(0)
     net = SparseUResNet(flags).to(dev).train(); net.executor_flags = fl
     g = parallel.FlatGradients(net); opt = parallel.FlatAdam(g, lr=1e-3)
@@ -27,11 +27,11 @@ for name, fl in (('default', 0), ('slab stats', 4)):
 for s in variants.values():
     for _ in range(5): s()
 res = {k: [] for k in variants}
-kernels = {'split always': 2, 'split auto': 1}
+kernels = {'group 1': 1, 'group 2': 2, 'group 4': 4, 'group 8': 8, 'group 16': 16}
 res = {(k, kn): [] for k in variants for kn in kernels}
 for rnd in range(4):
     for kn, kv in kernels.items():
-        L.urn_set_option(b'dw_split', kv)
+        L.urn_set_option(b'dw_group', kv)
         for k, s in variants.items():
             for _ in range(2): s()
             torch.cuda.synchronize(); t0 = time.perf_counter()

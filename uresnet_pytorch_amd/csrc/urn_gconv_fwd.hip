@@ -253,7 +253,7 @@ struct Pick { int mb, nb; };
 // tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
 // before the column tile is widened
 extern long g_lds_min_wgs;
-extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split;
+extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group;
 static int g_opt_dbg = 0;
 static int g_opt_fin_in_kernel = 0;
 static int g_opt_pipe = 0;
@@ -275,6 +275,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "tile_il")) { g_tile_il = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_kernel")) { g_dw_kernel = value == 1 ? 1 : 2; return URN_OK; }
     if (!strcmp(key, "dw_split")) { g_dw_split = (int)value; return URN_OK; }
+    if (!strcmp(key, "dw_group")) { g_dw_group = value > 0 ? (int)value : 1; return URN_OK; }
     if (!strcmp(key, "dw_blocks")) { g_dw_blocks = value > 0 ? (int)value : 2048; return URN_OK; }
     if (!strcmp(key, "fin_in_kernel")) { g_opt_fin_in_kernel = value != 0; return URN_OK; }
     urn_set_error("urn_set_option: unknown key %s", key);

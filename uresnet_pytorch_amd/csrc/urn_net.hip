@@ -15,6 +15,8 @@
 #include <memory>
 #include <vector>
 
+int g_dw_group = 1;   // weight gradients per fork to the side stream (urn_set_option "dw_group"); measured: 1: 3.61 ms, 2: 3.66, 4: 3.64, 8: 3.74, 16: 3.85
+
 namespace {
 
 struct Arena {
@@ -378,8 +380,14 @@ struct urn_net {
         }
         return y;
     }
-    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out)
+    // Weight gradients go to the side stream behind a fork (event record on the main stream, wait on the side stream).
+    // They can be queued and forked in groups (g_dw_group > 1) -- measured slower: the later a weight gradient
+    // starts, the less of it overlaps with the dX chain -- so the default is one fork per convolution.
+    struct DwJob { ConvP *c; const BNP *xf; const float *dy; const int32_t *tbl_f; int64_t n_out; };
+    std::vector<DwJob> dw_queue;
+    void dw_flush()
     {
+        if (dw_queue.empty()) return;
         hipStream_t ws = st;
         if (side && !events.empty()) {
             hipEvent_t e = events[ev_next++ % events.size()];
@@ -388,8 +396,15 @@ struct urn_net {
                 side_used = true;
             }
         }
-        check(urn_gconv_bwd_dw_ex(c.x, xf ? xf->scale : nullptr, xf ? xf->shift : nullptr, dy, tbl_f, geo.ld, c.K, n_out,
-                                  c.cin, c.cout, grads + c.w, ws));
+        for (const DwJob &j : dw_queue)
+            check(urn_gconv_bwd_dw_ex(j.c->x, j.xf ? j.xf->scale : nullptr, j.xf ? j.xf->shift : nullptr, j.dy, j.tbl_f, geo.ld,
+                                      j.c->K, j.n_out, j.c->cin, j.c->cout, grads + j.c->w, ws));
+        dw_queue.clear();
+    }
+    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out)
+    {
+        dw_queue.push_back(DwJob{&c, xf, dy, tbl_f, n_out});
+        if ((int)dw_queue.size() >= g_dw_group) dw_flush();
     }
     // backward of conv(BNReLU_b(x)): returns d/dx (raw input of the BatchNorm), adds `extra` when given
     float *conv_b_fused(ConvP &c, BNP &b, const float *dy, const int32_t *tbl_f, const int32_t *tbl_b, int flip_b,
@@ -693,6 +708,7 @@ static void run_backward(urn_net *net, const float *d_rows)
     d = net->fused ? net->u_b(net->u, d, 0) : net->u_bwd(net->u, d, 0);
     net->conv_bwd(net->stem, d, net->geo.nbr[0], net->geo.nbr[0], 1, n0, n0, false);
     // join: the caller's stream continues only after every weight gradient has landed
+    if (net->live()) net->dw_flush();
     if (net->side_used && net->live()) {
         hipEvent_t e = net->events[net->ev_next++ % net->events.size()];
         net->check(hipEventRecord(e, net->side) == hipSuccess && hipStreamWaitEvent(net->st, e, 0) == hipSuccess ? URN_OK : URN_EHIP);
