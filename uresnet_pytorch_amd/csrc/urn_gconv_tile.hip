@@ -421,12 +421,21 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     (void)tile_row0;
 }
 
-// Ring depth (steps of operands in flight per workgroup); urn_set_option("tile_depth", 2) selects the deeper ring.
-// Measured on the cfg3 shapes (tools/bench_gconv.py depth): depth 1, 2 and 4 are within 1 us of each other for every
-// layer -- the offset step is not bound by load latency but by the sum of its phases (tools/ablate_gconv.py) -- so the
-// default is the smallest kernel.
-int g_tile_depth = 0;
-int g_tile_il = 1;            // interleaved step for KS >= URN_IL_MIN_KS (urn_set_option("tile_il", 0) = plain step)
+// Ring depth of the plain (not interleaved) step: measured on the cfg3 shapes, depth 1, 2 and 4 were within 1 us of each
+// other for every layer -- the offset step is not bound by load latency but by the sum of its phases
+// (tools/ablate_gconv.py) -- so only depth 1 is instantiated; the interleaved step uses a two-slot ring.
+// The file is compiled three times (Makefile: -DURN_TILE_PART=0/1/2), each part instantiating the kernels of some
+// channel-step widths KS, so that the build parallelises; part 0 also holds the globals and the dispatcher.
+#ifndef URN_TILE_PART
+#define URN_TILE_PART 0
+#endif
+#if URN_TILE_PART == 0
+#define URN_TILE_GLOBAL(decl, init) decl = init
+#else
+#define URN_TILE_GLOBAL(decl, init) extern decl
+#endif
+URN_TILE_GLOBAL(int g_tile_depth, 0);   // kept for the option table; no effect
+URN_TILE_GLOBAL(int g_tile_il, 1);            // interleaved step for KS >= URN_IL_MIN_KS (urn_set_option("tile_il", 0) = plain step)
 #define URN_IL_MIN_KS 2
 
 template <int KS, int RB, int CB>
@@ -442,16 +451,15 @@ static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
             return (int)bx;
         }
     }
-    if (g_tile_depth >= 2) hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 1>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 1>), grid, block, 0, st, a);
     return (int)bx;
 }
 
-int g_tile_rb = 0, g_tile_cb = 0, g_tile_kc = 0;   // tuning knobs (urn_set_option "tile_rb" / "tile_cb" / "tile_kc"), 0 = automatic
+URN_TILE_GLOBAL(int g_tile_rb, 0); URN_TILE_GLOBAL(int g_tile_cb, 0); URN_TILE_GLOBAL(int g_tile_kc, 0);   // tuning knobs (urn_set_option "tile_rb" / "tile_cb" / "tile_kc"), 0 = automatic
 
 // returns the number of partial rows (workgroups along the rows), 0 when the shape has no instantiation
 template <int KS>
-static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
+int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
 {
     const long blocks16 = (n_out + 15) / 16;
     // Tile choice (measured sweep on MI355X, tools/bench_gconv.py): take all column blocks when there are <= 5 (the
@@ -499,6 +507,18 @@ static int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
     return 0;
 }
 
+// explicit instantiations of this part; the others are declared for the dispatcher
+#define URN_TILE_INST(KSv) template int launch_tile_ks<KSv>(const GArgs &, long, int, hipStream_t);
+#define URN_TILE_DECL(KSv) extern template int launch_tile_ks<KSv>(const GArgs &, long, int, hipStream_t);
+#if URN_TILE_PART == 0
+URN_TILE_INST(1) URN_TILE_INST(2) URN_TILE_INST(3) URN_TILE_DECL(4) URN_TILE_DECL(5) URN_TILE_DECL(6) URN_TILE_DECL(7)
+#elif URN_TILE_PART == 1
+URN_TILE_INST(4) URN_TILE_INST(5)
+#else
+URN_TILE_INST(6) URN_TILE_INST(7)
+#endif
+
+#if URN_TILE_PART == 0
 int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st)
 {
     const int nblk = a.cout / 16;
@@ -512,7 +532,7 @@ int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st)
         for (int d : {7, 6, 5, 4, 3, 2})
             if (ks % d == 0) { kc = d; break; }
     }
-    if (g_tile_kc > 0 && g_tile_kc <= 8 && ks % g_tile_kc == 0) kc = g_tile_kc;
+    if (g_tile_kc > 0 && g_tile_kc <= 7 && ks % g_tile_kc == 0) kc = g_tile_kc;
     switch (kc) {
     case 1: return launch_tile_ks<1>(a, n_out, nblk, st);
     case 2: return launch_tile_ks<2>(a, n_out, nblk, st);
@@ -521,7 +541,7 @@ int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st)
     case 5: return launch_tile_ks<5>(a, n_out, nblk, st);
     case 6: return launch_tile_ks<6>(a, n_out, nblk, st);
     case 7: return launch_tile_ks<7>(a, n_out, nblk, st);
-    case 8: return launch_tile_ks<8>(a, n_out, nblk, st);
     default: return 0;
     }
 }
+#endif   // URN_TILE_PART == 0
