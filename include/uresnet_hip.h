@@ -187,6 +187,10 @@ typedef struct {
     int64_t xs_n;
     const float *xs_gamma, *xs_beta;
     float *xs_mean, *xs_invstd, *xs_scale, *xs_shift, *xs_running_mean, *xs_running_var;
+    /* MFMA operand precision of this call: 0 = the library default (fp32 unless urn_set_option("gconv_precision", p)),
+     * 1 = fp32 explicitly, 2 = bf16, 3 = fp16.  Reduced precision rounds the gathered rows and the weights (RNE) while
+     * they are staged in LDS; tensors in HBM and the accumulation stay fp32 (BASELINE configs[1] bf16, configs[4] fp16). */
+    int precision;
 } urn_gconv_args;
 int64_t urn_gconv_part_bytes(int64_t n_out, int cout);
 int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);

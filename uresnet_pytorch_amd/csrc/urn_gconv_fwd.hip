@@ -253,6 +253,7 @@ struct Pick { int mb, nb; };
 // tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
 // before the column tile is widened
 extern long g_lds_min_wgs;
+int g_opt_precision = 0;   // default MFMA operand precision of the gather convolutions: 0 fp32, 1 bf16, 2 fp16
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group;
 static int g_opt_dbg = 0;
 static int g_opt_fin_in_kernel = 0;
@@ -273,6 +274,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "tile_kc")) { g_tile_kc = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_depth")) { g_tile_depth = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_il")) { g_tile_il = (int)value; return URN_OK; }
+    if (!strcmp(key, "gconv_precision")) { g_opt_precision = value >= 0 && value <= 2 ? (int)value : 0; return URN_OK; }
     if (!strcmp(key, "dw_kernel")) { g_dw_kernel = value == 1 ? 1 : 2; return URN_OK; }
     if (!strcmp(key, "dw_split")) { g_dw_split = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_group")) { g_dw_group = value > 0 ? (int)value : 1; return URN_OK; }
@@ -373,6 +375,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     a.cout = u->cout; a.cin = u->cin; a.res = u->res; a.y = u->y; a.xf_scale = u->xf_scale; a.xf_shift = u->xf_shift; a.epi = u->epilogue;
     a.part = u->part; a.e_x = u->e_x; a.e_scale = u->e_scale; a.e_shift = u->e_shift; a.e_mean = u->e_mean;
     a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg;
+    a.prec = u->precision > 0 ? u->precision - 1 : g_opt_precision;   // 0 fp32, 1 bf16, 2 fp16
     // finalize requested?  In-kernel (last workgroup) only on request: measured on MI355X the tail work (every
     // workgroup drains its stores and takes a ticket, the last one reduces the slab while the chip idles) costs
     // more than the separate finalize launch it saves (6.58 vs 6.14 ms per cfg3 step), so the default is launches.
@@ -404,7 +407,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_GCONV, st);
     bool ok = false;
-    if ((g_opt_kernel == 6 && !in_kernel) || sums_mode) {
+    if ((g_opt_kernel == 6 && !in_kernel) || sums_mode || a.prec) {
         const int np6 = urn_gconv_tile_launch(a, ks, u->n_out, st);
         if (np6 > 0) {
             if (prof) urn_prof_end(st);

@@ -26,7 +26,10 @@ __device__ __forceinline__ void static_for(F &&f)
 // ABL: timing-only ablation of the probe instantiations (1 no MFMA, 2 no global loads, 4 no LDS parking, 8 no barrier)
 // IL: straight-line step (no branches) with the loads of step +2 and the parking of step +1 interleaved between the
 //     MFMAs of the current step; 1 = plain input rows, 2 = relu(x*scale+shift) on the input rows.  Needs D == 2.
-template <int KS, int RB, int CB, int D, int STAMP = 0, int ABL = 0, int IL = 0>
+// PREC: operand precision of the MFMAs (interleaved variant only): 0 = fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16, 2 = fp16
+//       (one v_mfma_f32_16x16x16 per 16-channel group): rows and weights are read as fp32 from HBM and rounded (RNE)
+//       while they are parked in LDS, accumulation stays fp32 -- BASELINE configs[1] (bf16) and configs[4] (fp16).
+template <int KS, int RB, int CB, int D, int STAMP = 0, int ABL = 0, int IL = 0, int PREC = 0>
 __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 {
     constexpr int CIN = KS * 16;                                    // channels per step (a chunk of g.cin)
@@ -37,8 +40,24 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     __shared__ int s_idx[RB][28 * 16];
     __shared__ unsigned s_mask[RB];
     __shared__ float s_xf[2][512];                                  // folded BatchNorm affine of all input channels
-    __shared__ __attribute__((aligned(16))) float s_a[2][RB * 16][LDA];
-    __shared__ __attribute__((aligned(16))) float s_b[2][CB * 16][LDA];
+    static_assert(PREC == 0 || IL != 0, "reduced precision is implemented in the interleaved variant");
+    constexpr int LDS_LD = PREC ? CIN / 2 + 4 : LDA;                // floats per LDS row (16-bit rows: CIN + 8 halves)
+    __shared__ __attribute__((aligned(16))) float s_a[2][RB * 16][LDS_LD];
+    __shared__ __attribute__((aligned(16))) float s_b[2][CB * 16][LDS_LD];
+    // store four consecutive channels of an operand row in the LDS image (fp32, or rounded to 16 bits)
+    auto lds_store = [&](float *row_ptr, int c4, f32x4 v) {
+        if constexpr (PREC == 0) {
+            *(f32x4 *)(row_ptr + 4 * c4) = v;
+        } else if constexpr (PREC == 1) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 h = __builtin_convertvector(v, bf16x4);
+            *(uint2 *)((unsigned short *)row_ptr + 4 * c4) = __builtin_bit_cast(uint2, h);
+        } else {
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+            const h16x4 h = __builtin_convertvector(v, h16x4);
+            *(uint2 *)((unsigned short *)row_ptr + 4 * c4) = __builtin_bit_cast(uint2, h);
+        }
+    };
     __shared__ double s_p[2][RB][CB * 16];
 
     const long n_out = g.n_dev ? (long)*g.n_dev : g.n_cap;
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = have ? v[k] : 0.f;
-                *(f32x4 *)&s_a[buf][row][4 * c4] = v;
+                lds_store(&s_a[buf][row][0], c4, v);
             }
         }
 #pragma unroll
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             const int e = j * T + tid;
             if (B_TOT % T == 0 || e < B_TOT) {
                 const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
-                *(f32x4 *)&s_b[buf][col][4 * c4] = rb_[gi][j];
+                lds_store(&s_b[buf][col][0], c4, rb_[gi][j]);
             }
         }
     };
@@ -301,13 +320,13 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = have ? v[k] : 0.f;
-        *(f32x4 *)&s_a[pbuf][row][4 * c4] = v;
+        lds_store(&s_a[pbuf][row][0], c4, v);
     };
     auto piece_park_b = [&](int pbuf, auto slot, auto jj) {
         constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
         const int e = (B_TOT % T == 0) ? j * T + tid : min(j * T + tid, B_TOT - 1);
         const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
-        *(f32x4 *)&s_b[pbuf][col][4 * c4] = rb_[gi][j];
+        lds_store(&s_b[pbuf][col][0], c4, rb_[gi][j]);
     };
     auto step_il = [&](auto slot) {
         constexpr int u = decltype(slot)::value;
@@ -341,12 +360,28 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         constexpr int PER = (NP - P0 + KS - 1) / KS;               // pieces after each group of four MFMAs
         auto group = [&](auto kk) {
             constexpr int ks = decltype(kk)::value;
-            const f32x4 a = *(const f32x4 *)&s_a[buf][rb * 16 + r][ks * 16 + 4 * q];
-            const f32x4 b = *(const f32x4 *)&s_b[buf][cb * 16 + r][ks * 16 + 4 * q];
-            // two accumulators, alternating per MFMA: consecutive MFMAs are independent (measured 22 vs 24 us at
-            // level 3, 64 -> 64, against one accumulator per group of four)
-            acc = MFMA16(a[0], b[0], acc); acc2 = MFMA16(a[1], b[1], acc2);
-            acc = MFMA16(a[2], b[2], acc); acc2 = MFMA16(a[3], b[3], acc2);
+            if constexpr (PREC == 0) {
+                const f32x4 a = *(const f32x4 *)&s_a[buf][rb * 16 + r][ks * 16 + 4 * q];
+                const f32x4 b = *(const f32x4 *)&s_b[buf][cb * 16 + r][ks * 16 + 4 * q];
+                // two accumulators, alternating per MFMA: consecutive MFMAs are independent (measured 22 vs 24 us at
+                // level 3, 64 -> 64, against one accumulator per group of four)
+                acc = MFMA16(a[0], b[0], acc); acc2 = MFMA16(a[1], b[1], acc2);
+                acc = MFMA16(a[2], b[2], acc); acc2 = MFMA16(a[3], b[3], acc2);
+            } else {
+                // 16-bit operands: lane (r, q) holds the four k-values 4q..4q+3 of the 16-channel group, one MFMA per group
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                const s16x4 a = *(const s16x4 *)((const unsigned short *)&s_a[buf][rb * 16 + r][0] + ks * 16 + 4 * q);
+                const s16x4 b = *(const s16x4 *)((const unsigned short *)&s_b[buf][cb * 16 + r][0] + ks * 16 + 4 * q);
+                if constexpr (PREC == 1) {
+                    if constexpr (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+                } else {
+                    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                    const h16x4 ah = __builtin_bit_cast(h16x4, a), bh = __builtin_bit_cast(h16x4, b);
+                    if constexpr (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+                }
+            }
             static_for<P0 + ks * PER, (P0 + (ks + 1) * PER < NP ? P0 + (ks + 1) * PER : NP)>(piece);
         };
         static_for<0, KS>(group);
@@ -443,6 +478,19 @@ static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
 {
     const long bx = (n_out + 16 * RB - 1) / (16 * RB);
     const dim3 grid((unsigned)bx, a.cout / (16 * CB)), block(64 * RB * CB);
+    {
+        const bool xfm = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
+        if (a.prec == 1) {
+            if (xfm) hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2, 0, 0, 2, 1>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2, 0, 0, 1, 1>), grid, block, 0, st, a);
+            return (int)bx;
+        }
+        if (a.prec == 2) {
+            if (xfm) hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2, 0, 0, 2, 2>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2, 0, 0, 1, 2>), grid, block, 0, st, a);
+            return (int)bx;
+        }
+    }
     if constexpr (KS >= URN_IL_MIN_KS) {
         if (g_tile_il) {
             const bool xfm = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;

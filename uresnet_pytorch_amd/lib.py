@@ -34,7 +34,7 @@ class GConvArgs(ctypes.Structure):
                 ('xs_ld', ctypes.c_int * 2), ('xs_sums', ctypes.c_void_p * 2), ('xs_n', ctypes.c_int64),
                 ('xs_gamma', ctypes.c_void_p), ('xs_beta', ctypes.c_void_p), ('xs_mean', ctypes.c_void_p),
                 ('xs_invstd', ctypes.c_void_p), ('xs_scale', ctypes.c_void_p), ('xs_shift', ctypes.c_void_p),
-                ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p)]
+                ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p), ('precision', ctypes.c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/uresnet_hip.h
