@@ -124,3 +124,33 @@ def test_dense_gpu_route_mfma_channels_vs_cpu_route(S, uns, B):
         if e > worst:
             worst, worst_k = e, k
     assert worst < 3e-2, (worst_k, worst)
+
+
+@pytest.mark.gpu
+def test_dense_gpu_route_bf16_operands():
+    """BASELINE configs[1] dtype: the dense model with bf16 MFMA operands (flags PRECISION='bf16'; fp32 tensors and
+    accumulation) against the fp32 CPU route: forward 5e-2 norm-wise (bf16 unit roundoff 3.9e-3 through ~30 conv+BN
+    layers), loss 2e-2."""
+    from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+    from uresnet_pytorch_amd import lib as L_
+    dev = torch.device('cuda:0')
+    S, uns, B = 32, 3, 2
+    mk = lambda prec: SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=uns, SPATIAL_SIZE=S, NUM_CLASS=5,
+                                      BN_MOMENTUM=0.9, PRECISION=prec)
+    torch.manual_seed(1)
+    cpu = DenseUResNet(mk('fp32')).train()
+    gpu = DenseUResNet(mk('bf16')).to(dev).train()
+    gpu.load_state_dict(cpu.state_dict())
+    blob = make_dense_blob(list(range(B)), S, 3)
+    x, lab = torch.from_numpy(blob['data']), torch.from_numpy(blob['label'])
+    try:
+        out_c = cpu(x); loss_c, _ = DenseSegmentationLoss(mk('fp32'))(list(out_c), list(x), list(lab), None)
+        xg, lg = x.to(dev), lab.to(dev)
+        out_g = gpu(xg); loss_g, _ = DenseSegmentationLoss(mk('bf16'))(list(out_g), list(xg), list(lg), None)
+        loss_g.backward()
+        e = rel(out_g.detach().cpu().numpy(), out_c.detach().numpy())
+        assert 1e-5 < e < 5e-2, e      # > 1e-5: the bf16 kernels really ran
+        assert abs(loss_g.item() - loss_c.item()) < 2e-2 * abs(loss_c.item())
+        assert all(torch.isfinite(p.grad).all() for p in gpu.parameters() if p.grad is not None)
+    finally:
+        L_.set_precision('fp32')

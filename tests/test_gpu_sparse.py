@@ -523,3 +523,61 @@ def test_flat_adam_matches_torch_adam(dev):
     for k in sb['state']:
         assert rel(sa['state'][k]['exp_avg_sq'].cpu().numpy(), sb['state'][k]['exp_avg_sq'].cpu().numpy()) < 1e-6
         assert float(sa['state'][k]['step']) == float(sb['state'][k]['step'])
+
+
+@pytest.mark.parametrize('prec,tol_op,tol_net', [('bf16', 6e-3, 5e-2), ('fp16', 8e-4, 8e-3)])
+def test_reduced_precision_operands(dev, prec, tol_op, tol_net):
+    """BASELINE configs[1] (bf16) / configs[4] (fp16): MFMA operands rounded to 16 bits while they are staged in LDS,
+    fp32 tensors and accumulation.  Each operator against the fp64 oracle: bf16 has 8 significand bits (unit roundoff
+    3.9e-3, observed norm-wise error 2.4e-3), fp16 has 11 (4.9e-4, observed 2.9e-4); the small network end to end."""
+    from uresnet_pytorch_amd import lib as L_, sparse_ops as so
+    from uresnet_pytorch_amd.models import SparseSegmentationLoss
+    L = L_.load()
+    try:
+        L_.set_precision(prec)
+        S, cin, cout = 32, 32, 48
+        c, f = cloud(9, S, 1500, 2, 0)
+        geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
+        ref = orc.Geometry(c, f, S, 1)
+        n = ref.n[0]
+        rng = np.random.default_rng(5)
+        x = rng.normal(size=(n, cin)).astype(np.float32)
+        W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+        dy = rng.normal(size=(n, cout)).astype(np.float32)
+        xt = torch.from_numpy(x).to(dev).requires_grad_(True); Wt = torch.from_numpy(W).to(dev).requires_grad_(True)
+        y = so.GConvFunction.apply(xt, Wt, None, geo.nbr[0], geo.nbr[0], 1, geo.ld, n, n)
+        y.backward(torch.from_numpy(dy).to(dev))
+        y_ref = orc.conv_fwd(x, W, ref.nbr[0])
+        dx_ref, dW_ref = orc.conv_bwd(x, W, ref.nbr[0], dy, ref.nbr_inv[0])
+        for got, want in ((y.detach(), y_ref), (xt.grad, dx_ref), (Wt.grad, dW_ref)):
+            e = rel(got.cpu().numpy(), want)
+            assert 1e-6 < e < tol_op, e      # > 1e-6: the reduced-precision kernels really ran
+        # whole network (executor, fused BatchNorm) against the oracle
+        S, m, Lv, nc = 32, 16, 3, 5
+        c, f = cloud(6, S, 800, 2, 11)
+        pc = np.concatenate([c.astype(np.float32), f], 1)
+        lab = np.random.default_rng(3).integers(0, nc, size=(len(pc), 1)).astype(np.float32)
+        flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=nc, PRECISION=prec)
+        P = orc.init_params(m, Lv, nc, seed=1)
+        net = make_model(flags, P, dev)
+        data = torch.from_numpy(pc).to(dev); label = torch.from_numpy(lab).to(dev)
+        out = net(data)
+        loss, acc = SparseSegmentationLoss(flags)(out, [data], [label], None)
+        loss.backward()
+        oref = orc.SparseUResNetOracle(P, m, Lv, nc, S)
+        logits_ref = oref.forward(pc)
+        loss_ref, _, dl = orc.segmentation_loss(logits_ref, pc, lab)
+        G, _ = oref.backward(dl)
+        assert rel(out[0].detach().cpu().numpy(), logits_ref) < tol_net
+        assert abs(loss.item() - loss_ref) < tol_net * abs(loss_ref)
+        # gradients: norm-wise over ALL parameters (single small tensors -- a BatchNorm shift deep in the U -- see many
+        # ReLU-mask flips at this precision and are individually much noisier)
+        got = np.concatenate([p.grad.cpu().numpy().ravel() for k, p in net.named_parameters()])
+        want = np.concatenate([np.asarray(G[k]).ravel() for k, p in net.named_parameters()])
+        # (BatchNorm backward subtracts two means from the gradient: that cancellation amplifies the operand rounding;
+        # observed 0.16 for bf16 and 0.054 for fp16 on this network -- fp16 additionally loses the smallest gradient
+        # values, ~1e-6 here, to its narrow exponent range; no loss scaling is applied.  The strict bounds are the
+        # per-operator ones above.)
+        assert rel(got, want) < 8 * tol_net, rel(got, want)
+    finally:
+        L_.set_precision('fp32')

@@ -31,3 +31,28 @@ for lv, ci, co in ((0, 16, 16), (1, 32, 32), (2, 48, 48), (3, 64, 64), (4, 80, 8
     print('L%d %3d->%3d  fp32 %5.1f us | bf16 %5.1f us rel err %.1e | fp16 %5.1f us rel err %.1e' % (
         lv, ci, co, res['fp32'][1], res['bf16'][1], float((res['bf16'][0].double() - ref).norm() / ref.norm()),
         res['fp16'][1], float((res['fp16'][0].double() - ref).norm() / ref.norm())), flush=True)
+print('weight gradient:')
+def run_dw(args, reps=20):
+    for _ in range(2): L_.check(L.urn_gconv_bwd_dw(*args))
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): L_.check(L.urn_gconv_bwd_dw(*args))
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+for lv, ci, co in ((0, 16, 16), (1, 32, 32), (1, 16, 32), (2, 48, 48), (3, 64, 64), (4, 80, 80), (3, 128, 64), (4, 160, 80)):
+    n = geo.n[lv]
+    x = torch.randn(n, ci, device=dev); dy = torch.randn(n, co, device=dev)
+    res = {}
+    for name, prec in (('fp32', 0), ('bf16', 1), ('fp16', 2)):
+        L.urn_set_option(b'gconv_precision', prec)
+        dw = torch.zeros(27, ci, co, device=dev)
+        args = (x.data_ptr(), dy.data_ptr(), geo.nbr[lv].data_ptr(), geo.ld, 27, n, ci, co, dw.data_ptr(), L_.stream())
+        L_.check(L.urn_gconv_bwd_dw(*args)); torch.cuda.synchronize()
+        first = dw.clone()
+        res[name] = (first, min(run_dw(args) for _ in range(3)))
+    L.urn_set_option(b'gconv_precision', 0)
+    ref = res['fp32'][0].double()
+    print('L%d %3d->%3d  fp32 %5.1f us | bf16 %5.1f us rel err %.1e | fp16 %5.1f us rel err %.1e' % (
+        lv, ci, co, res['fp32'][1], res['bf16'][1], float((res['bf16'][0].double() - ref).norm() / ref.norm()),
+        res['fp16'][1], float((res['fp16'][0].double() - ref).norm() / ref.norm())), flush=True)

@@ -7,6 +7,9 @@ from uresnet_pytorch_amd import parallel
 from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
 from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
 dev = torch.device('cuda:0')
+from uresnet_pytorch_amd import lib as _l
+if len(sys.argv) > 5:
+    _l.load().urn_set_option(b'gconv_precision', int(sys.argv[5]))   # 0 fp32, 1 bf16, 2 fp16
 S, n, m, Lv = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=5)
 blob = make_sparse_blob([0], S, n)
@@ -14,7 +17,7 @@ data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['la
 torch.manual_seed(0)
 net = SparseUResNet(flags).to(dev).train()
 print('params', sum(p.numel() for p in net.parameters()))
-g = parallel.FlatGradients(net); opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+g = parallel.FlatGradients(net); opt = parallel.FlatAdam(g, lr=1e-3)
 crit = SparseSegmentationLoss(flags)
 def step():
     g.zero(); out = net(data); loss, _ = crit(out, [data], [label], None); loss.backward(); opt.step(); return loss

@@ -193,7 +193,10 @@ __global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, c
 // KT = pairs per batch: 32 for tiles of >= 3 output blocks; narrow tiles take bigger batches and split the batch's
 // pairs (the contraction dimension) over the waves, which would otherwise all compute the same block: one block
 // (16 x 16 channels): 128 pairs, 4 waves x 8 k-steps; two blocks (16 x 32, 32 x 16): 64 pairs, 2 waves per block.
-template <int S, int XF, int KT>
+// PREC: MFMA operand precision, 0 fp32, 1 bf16, 2 fp16 (as in the forward kernel): the staged rows are rounded while they
+//       are parked; a fragment = four consecutive PAIRS of one channel, assembled from four 16-bit LDS reads
+//       (v_mfma_f32_16x16x16: one MFMA per 16 pairs instead of four).
+template <int S, int XF, int KT, int PREC = 0>
 __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, const float *__restrict__ xf_scale,
                                                    const float *__restrict__ xf_shift, const float *__restrict__ dy,
                                                    const int *__restrict__ tbl, long ld, long n_out, int cin,
@@ -205,8 +208,22 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
     // leading dimensions = 16 mod 32 floats, so that the four pair rows of a fragment read fall on different banks
     constexpr int A_LD = KT == 32 ? DW_MAXI * 16 + 16 : (KT == 64 ? 48 : 16);
     constexpr int B_LD = KT == 32 ? DW_MAXN * 16 + 32 : (KT == 64 ? 48 : 16);
-    __shared__ __attribute__((aligned(16))) float s_a[2][KT][A_LD];
-    __shared__ __attribute__((aligned(16))) float s_b[2][KT][B_LD];
+    // 16-bit operands: the same row length in elements, i.e. half the floats per row
+    __shared__ __attribute__((aligned(16))) float s_a[2][KT][PREC ? A_LD / 2 : A_LD];
+    __shared__ __attribute__((aligned(16))) float s_b[2][KT][PREC ? B_LD / 2 : B_LD];
+    auto lds_store = [&](float *row_ptr, int c4, f32x4 v) {
+        if constexpr (PREC == 0) {
+            *(f32x4 *)(row_ptr + 4 * c4) = v;
+        } else if constexpr (PREC == 1) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 h = __builtin_convertvector(v, bf16x4);
+            *(uint2 *)((unsigned short *)row_ptr + 4 * c4) = __builtin_bit_cast(uint2, h);
+        } else {
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+            const h16x4 h = __builtin_convertvector(v, h16x4);
+            *(uint2 *)((unsigned short *)row_ptr + 4 * c4) = __builtin_bit_cast(uint2, h);
+        }
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
@@ -227,7 +244,8 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
         mi_[s] = blk / ni_n; ni_[s] = blk - mi_[s] * ni_n;
     }
     constexpr int WPB = KT == 128 ? 4 : (KT == 64 ? 2 : 1);   // waves per block
-    constexpr int KSW = KT / 4 / WPB;                           // k-steps (of four pairs) per wave and batch
+    constexpr int KPM = PREC ? 16 : 4;                          // pairs contracted by one MFMA
+    constexpr int KSW = KT / KPM / WPB;                         // k-steps per wave and batch
     const int ks0 = KT == 32 ? 0 : (wave / (4 / WPB)) * KSW;
     // what this thread moves per batch: two 16-byte pieces of the x rows, three of the dy rows
     const int a_tot = KT * (ci_w / 4), b_tot = KT * (co_w / 4);
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = a_rr[j] < nb ? v[k] : 0.f;   // zero-fill the tail of the last batch
-            *(f32x4 *)&s_a[buf][a_rr[j]][4 * a_c4[j]] = v;
+            lds_store(&s_a[buf][a_rr[j]][0], a_c4[j], v);
         };
         auto park_b = [&](int b, int buf, auto slot, auto jj) {
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
             f32x4 v = rb[u][j];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = b_rr[j] < nb ? v[k] : 0.f;
-            *(f32x4 *)&s_b[buf][b_rr[j]][4 * b_c4[j]] = v;
+            lds_store(&s_b[buf][b_rr[j]][0], b_c4[j], v);
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -350,9 +368,26 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
 #pragma unroll
                 for (int kk = 0; kk < KSW; ++kk) {
                     const int ks = ks0 + kk;
-                    const float av = s_a[buf][4 * ks + q][mi_[sl] * 16 + m];
-                    const float bv = s_b[buf][4 * ks + q][ni_[sl] * 16 + m];
-                    acc[sl] = MFMA16(av, bv, acc[sl]);
+                    if constexpr (PREC == 0) {
+                        const float av = s_a[buf][4 * ks + q][mi_[sl] * 16 + m];
+                        const float bv = s_b[buf][4 * ks + q][ni_[sl] * 16 + m];
+                        acc[sl] = MFMA16(av, bv, acc[sl]);
+                    } else {
+                        typedef short s16x4 __attribute__((ext_vector_type(4)));
+                        s16x4 av, bv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {   // lane (m, q): pairs 16 ks + 4 q + i of channel m of the block
+                            av[i] = (short)((const unsigned short *)&s_a[buf][16 * ks + 4 * q + i][0])[mi_[sl] * 16 + m];
+                            bv[i] = (short)((const unsigned short *)&s_b[buf][16 * ks + 4 * q + i][0])[ni_[sl] * 16 + m];
+                        }
+                        if constexpr (PREC == 1) {
+                            acc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc[sl], 0, 0, 0);
+                        } else {
+                            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                            acc[sl] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, av), __builtin_bit_cast(h16x4, bv),
+                                                                            acc[sl], 0, 0, 0);
+                        }
+                    }
                 }
                 if constexpr (sl * PER + 0 < 10) piece(std::integral_constant<int, sl * PER + 0>());
                 if constexpr (PER > 1 && sl * PER + 1 < 10) piece(std::integral_constant<int, sl * PER + 1>());
@@ -432,6 +467,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw_small(const float *__restrict_
     }
 }
 
+extern int g_opt_precision;
 int g_dw_split = 1;       // split-batch variants of k_gconv_dw2 for one- and two-block tiles: 0 never, 1 automatic, 2 always (urn_set_option "dw_split")
 int g_dw_kernel = 2;      // 2 = k_gconv_dw2 (default), 1 = k_gconv_dw (urn_set_option "dw_kernel")
 int g_dw_blocks = 2048;   // target number of workgroups of the weight-gradient kernel (urn_set_option "dw_blocks")
@@ -472,17 +508,25 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_DW, st);
     const dim3 grid(chunks, K, n_ci_tiles * n_co_tiles);
+    const int prec = g_opt_precision;   // 0 fp32, 1 bf16, 2 fp16 (urn_set_option "gconv_precision")
     if (g_dw_kernel == 2) {
         const int ci_w = cin < DW_MAXI * 16 ? cin : DW_MAXI * 16, co_w = cout < DW_MAXN * 16 ? cout : DW_MAXN * 16;
         const int nblk_max = (ci_w / 16) * (co_w / 16);   // of the widest tile
         const int slots = (nblk_max + 3) / 4;
         // one- and two-block tiles exist only when the whole layer is that narrow (cin, cout <= 32): then every tile
         // of the grid has the same shape and the split-batch variants apply
+#define URN_DW2P(Sv, XFv, KTv)                                                                                                       \
+        do {                                                                                                                         \
+            if (prec == 1) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 1>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, \
+                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                             \
+            else if (prec == 2) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 2>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, \
+                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                   \
+            else hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 0>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
+                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                                                 \
+        } while (0)
 #define URN_DW2K(Sv, KTv)                                                                                                            \
-        if (xf_scale) hipLaunchKernelGGL((k_gconv_dw2<Sv, 1, KTv>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
-                                         (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                                            \
-        else hipLaunchKernelGGL((k_gconv_dw2<Sv, 0, KTv>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,          \
-                                (long)n_out, cin, cout, chunk, n_ci_tiles, dw);
+        if (xf_scale) URN_DW2P(Sv, 1, KTv);                                                                                          \
+        else URN_DW2P(Sv, 0, KTv);
 #define URN_DW2(Sv) case Sv: URN_DW2K(Sv, 32) break;
         // The split variants keep all four matrix pipes of a CU busy: faster alone (16 x 16 at 50k rows: 29 -> 24 us;
         // dense 128^3 model: 60.6 -> 49.6 ms per step), but in the sparse executor the weight gradients share the
@@ -493,6 +537,7 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
         else if (nblk_max == 2 && split) { URN_DW2K(1, 64) }
         else switch (slots) { URN_DW2(1) URN_DW2(2) URN_DW2(3) URN_DW2(4) URN_DW2(5) default: break; }
 #undef URN_DW2K
+#undef URN_DW2P
 #undef URN_DW2
     } else {
         hipLaunchKernelGGL(k_gconv_dw, grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,

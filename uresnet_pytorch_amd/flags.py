@@ -40,6 +40,7 @@ class URESNET_FLAGS:
     GPUS = []
     WEIGHT_PREFIX = ''
     NUM_POINT = 2048
+    PRECISION = 'fp32'
     NUM_CHANNEL = -1
     ITERATION = 10000
     REPORT_STEP = 100
@@ -90,6 +91,8 @@ class URESNET_FLAGS:
           help='Compute pixel loss weighting factor on the fly')
         a('-sd', '--seed', default=self.SEED, help='Seed for random number generators')
         a('-np', '--num_point', type=int, default=self.NUM_POINT, help='Active voxels per synthetic event')
+        a('-prec', '--precision', type=str, default=self.PRECISION, choices=['fp32', 'bf16', 'fp16'],
+          help='MFMA operand precision of the convolutions on the GPU (tensors and accumulation stay fp32)')
         return parser
 
     def _build_parsers(self):

@@ -150,3 +150,13 @@ def require_gpu(t):
     if not t.is_cuda:
         raise RuntimeError('uresnet_pytorch_amd: the HIP path needs tensors on the GPU (got %s); '
                            'there is no CPU fallback' % t.device)
+
+
+PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp16': 2}
+
+
+def set_precision(name):
+    """MFMA operand precision of the gather convolutions (forward, input gradient, weight gradient): the library
+    default that calls without an explicit urn_gconv_args.precision use.  BASELINE configs[1] = 'bf16', configs[4] =
+    'fp16'; tensors in HBM and the accumulation stay fp32."""
+    load().urn_set_option(b'gconv_precision', PRECISIONS[name])

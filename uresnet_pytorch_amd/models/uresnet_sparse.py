@@ -8,6 +8,7 @@ import torch
 
 from ..utils import DeferredFloat
 
+from .. import lib as _lib
 from .. import scn
 from .. import sparse_ops as so
 from ..trunk import TrunkExecutor
@@ -57,6 +58,8 @@ class UResNet(torch.nn.Module):
         """point_cloud: (N, d+2) rows [x, y, z, batch_id, value]; returns [ (N, NUM_CLASS) ]."""
         coords = point_cloud[:, 0:-1].float()
         features = point_cloud[:, -1][:, None].float()
+        if coords.is_cuda:
+            _lib.set_precision(getattr(self._flags, 'PRECISION', 'fp32'))   # flags -prec: fp32 (default) | bf16 | fp16
         if self.use_executor and self.training and coords.is_cuda:
             x = self._trunk(coords, features)
         else:
