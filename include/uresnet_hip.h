@@ -191,6 +191,9 @@ typedef struct {
      * 1 = fp32 explicitly, 2 = bf16, 3 = fp16.  Reduced precision rounds the gathered rows and the weights (RNE) while
      * they are staged in LDS; tensors in HBM and the accumulation stay fp32 (BASELINE configs[1] bf16, configs[4] fp16). */
     int precision;
+    /* Row strides (in floats) of x and y when they are column blocks of wider row matrices -- the halves of a channel
+     * concat: 0 = dense (cin / cout).  res, e_x and the statistics slabs are always dense.  2-D tile kernel only. */
+    int64_t ldx, ldy;
 } urn_gconv_args;
 int64_t urn_gconv_part_bytes(int64_t n_out, int cout);
 int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);
@@ -198,6 +201,10 @@ int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);
 int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const float *xf_shift, const float *dy,
                         const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw,
                         void *stream);
+/* the same with a row stride ld_dy >= cout of dy (dy is a column block of a wider matrix) */
+int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy,
+                             const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw,
+                             void *stream);
 /* column partials of a tensor whose producer cannot fuse them (the 1-channel stem) */
 int urn_bn_stats_partial(const float *x, int64_t n, int c, double *part, int *n_part, void *stream);
 int urn_bn_finalize_fwd(const double *part, int n_part, int64_t n, int c, int part_ld, double eps,
@@ -210,8 +217,9 @@ int urn_bn_bwd_apply(const float *x, const float *g, const float *extra, int64_t
                      const float *gamma, const float *mean, const float *invstd, const float *coef0,
                      const float *coef1, float *dx, void *stream);
 /* the same with the coefficients taken from an accumulated slab ([slots][2][c], see part_slots): c0 = sum g / n,
- * c1 = sum g*xhat / n; dgamma/dbeta are ACCUMULATED into by the first workgroup.  c <= 512, c % 4 == 0. */
-int urn_bn_bwd_apply_sums(const float *x, const float *g, const float *extra, int64_t n, int c,
+ * c1 = sum g*xhat / n; dgamma/dbeta are ACCUMULATED into by the first workgroup.  c <= 512, c % 4 == 0.
+ * ld_extra = row stride of `extra` in floats (0 = c; larger when it is a column block of a wider matrix). */
+int urn_bn_bwd_apply_sums(const float *x, const float *g, const float *extra, int64_t ld_extra, int64_t n, int c,
                           const float *gamma, const float *mean, const float *invstd, const double *sums,
                           int slots, float *dgamma, float *dbeta, float *dx, void *stream);
 

@@ -381,11 +381,35 @@ def test_fused_conv_pieces_vs_oracle(dev):
     L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a5), ctypes.byref(npart), L_.stream()))
     assert torch.equal(g2, gbuf)
     dg2 = torch.zeros(cin, device=dev); db2 = torch.zeros(cin, device=dev); dx2 = torch.empty((n, cin), device=dev)
-    L_.check(L.urn_bn_bwd_apply_sums(xt.data_ptr(), g2.data_ptr(), et.data_ptr(), n, cin, gt.data_ptr(), mt.data_ptr(),
+    L_.check(L.urn_bn_bwd_apply_sums(xt.data_ptr(), g2.data_ptr(), et.data_ptr(), 0, n, cin, gt.data_ptr(), mt.data_ptr(),
                                      it.data_ptr(), sums_g.data_ptr(), SL, dg2.data_ptr(), db2.data_ptr(), dx2.data_ptr(),
                                      L_.stream()))
     assert rel(dx2.cpu().numpy(), dx_ref + extra) < 5 * TOL and rel(dx2.cpu().numpy(), dx.cpu().numpy()) < 1e-6
     assert rel(dg2.cpu().numpy(), dg_ref) < 5 * TOL and rel(db2.cpu().numpy(), db_ref) < 5 * TOL
+
+    # --- operands that are column blocks of wider row matrices (the halves of a channel concat) ----------------------
+    wide_y = torch.full((n, cout + 16), 7.0, device=dev)
+    a6 = A(x=xt.data_ptr(), wt=wt.data_ptr(), tbl=geo.nbr[0].data_ptr(), ld=geo.ld, K=27, flip=0, n_out=n, cin=cin, cout=cout,
+           y=wide_y.data_ptr() + 4 * 16, ldy=cout + 16, xf_scale=sc.data_ptr(), xf_shift=sh.data_ptr())
+    L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a6), None, L_.stream()))
+    assert torch.equal(wide_y[:, 16:], y) and bool((wide_y[:, :16] == 7.0).all())
+    wide_x = torch.randn((n, cin + 32), device=dev); wide_x[:, 32:] = xt
+    y3 = torch.empty((n, cout), device=dev)
+    a7 = A(x=wide_x.data_ptr() + 4 * 32, wt=wt.data_ptr(), tbl=geo.nbr[0].data_ptr(), ld=geo.ld, K=27, flip=0, n_out=n, cin=cin,
+           cout=cout, y=y3.data_ptr(), ldx=cin + 32, xf_scale=sc.data_ptr(), xf_shift=sh.data_ptr())
+    L_.check(L.urn_gconv_fwd_ex(ctypes.byref(a7), None, L_.stream()))
+    assert torch.equal(y3, y)
+    wide_dy = torch.randn((n, cout + 16), device=dev); wide_dy[:, 16:] = dyt
+    dW3 = torch.zeros_like(Wt)
+    L_.check(L.urn_gconv_bwd_dw_strided(xt.data_ptr(), sc.data_ptr(), sh.data_ptr(), wide_dy.data_ptr() + 4 * 16, cout + 16,
+                                        geo.nbr[0].data_ptr(), geo.ld, 27, n, cin, cout, dW3.data_ptr(), L_.stream()))
+    assert rel(dW3.cpu().numpy(), dW.cpu().numpy()) < 1e-6
+    wide_e = torch.randn((n, cin + 16), device=dev); wide_e[:, :cin] = et
+    dg3 = torch.zeros(cin, device=dev); db3 = torch.zeros(cin, device=dev); dx3 = torch.empty((n, cin), device=dev)
+    L_.check(L.urn_bn_bwd_apply_sums(xt.data_ptr(), g2.data_ptr(), wide_e.data_ptr(), cin + 16, n, cin, gt.data_ptr(), mt.data_ptr(),
+                                     it.data_ptr(), sums_g.data_ptr(), SL, dg3.data_ptr(), db3.data_ptr(), dx3.data_ptr(),
+                                     L_.stream()))
+    assert torch.equal(dx3, dx2)
 
 
 def test_executor_two_forwards_before_backward(dev):

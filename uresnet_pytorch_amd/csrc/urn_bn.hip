@@ -473,7 +473,7 @@ extern "C" int urn_bn_bwd_apply(const float *x, const float *g, const float *ext
 // accumulates dgamma/dbeta.  EPB elements per block so that the slab re-read stays small beside the stream.
 #define URN_APPLY_EPB 2048
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restrict__ x, const float *__restrict__ g,
-                                                           const float *__restrict__ extra, long total, int c,
+                                                           const float *__restrict__ extra, long ld_extra, long total, int c,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ mean,
                                                            const float *__restrict__ invstd,
@@ -491,7 +491,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restri
         xv[it] = gv[it] = ev[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (i < total) {   // c % 4 == 0: a vector never straddles rows
             xv[it] = *(const f32x4 *)(x + i); gv[it] = *(const f32x4 *)(g + i);
-            if (extra) ev[it] = *(const f32x4 *)(extra + i);
+            if (extra) {
+                const long row = i / c;                           // extra may be a column block of a wider matrix
+                ev[it] = *(const f32x4 *)(extra + row * ld_extra + (i - row * c));
+            }
         }
     }
     for (int e = threadIdx.x; e < c; e += 256) {
@@ -519,17 +522,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restri
     }
 }
 
-extern "C" int urn_bn_bwd_apply_sums(const float *x, const float *g, const float *extra, int64_t n, int c,
+extern "C" int urn_bn_bwd_apply_sums(const float *x, const float *g, const float *extra, int64_t ld_extra, int64_t n, int c,
                                      const float *gamma, const float *mean, const float *invstd, const double *sums,
                                      int slots, float *dgamma, float *dbeta, float *dx, void *stream)
 {
+    if (ld_extra <= 0) ld_extra = c;
+    URN_CHECK_ARG(ld_extra >= c && ld_extra % 4 == 0, "ld_extra smaller than the row or not a multiple of 4");
     URN_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 512 && n >= 0 && gamma && mean && invstd && sums && slots > 0 && dgamma && dbeta,
                   "bad argument (c must be a multiple of 4, at most 512)");
     const long total = (long)n * c;
     if (total == 0) return URN_OK;
     URN_CHECK_ARG(x && g && dx, "null pointer");
     hipLaunchKernelGGL(k_bn_bwd_apply_sums, dim3(urn_cdiv(total, URN_APPLY_EPB)), dim3(256), 0, (hipStream_t)stream, x, g, extra,
-                       total, c, gamma, mean, invstd, sums, slots, 1.0 / (double)n, dgamma, dbeta, dx);
+                       (long)ld_extra, total, c, gamma, mean, invstd, sums, slots, 1.0 / (double)n, dgamma, dbeta, dx);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }

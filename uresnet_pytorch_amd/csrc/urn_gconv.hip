@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
                                                    const float *__restrict__ xf_shift, const float *__restrict__ dy,
                                                    const int *__restrict__ tbl, long ld, long n_out, int cin,
                                                    int cout, long chunk, int n_ci_tiles,
-                                                   float *__restrict__ dw)
+                                                   float *__restrict__ dw, long ld_dy)
 {
     __shared__ int s_in[DW2_LIST], s_out[DW2_LIST];
     __shared__ int s_cnt[16];
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
         auto fetch_b = [&](int b, auto slot, auto jj) {
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
             const int p = min(b * KT + b_rr[j], cnt - 1);
-            rb[u][j] = *(const f32x4 *)(dy + (long)s_out[p] * cout + co0 + 4 * b_c4[j]);
+            rb[u][j] = *(const f32x4 *)(dy + (long)s_out[p] * ld_dy + co0 + 4 * b_c4[j]);
         };
         auto park_a = [&](int b, int buf, auto slot, auto jj) {
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
@@ -482,11 +482,23 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
                                    const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout,
                                    float *dw, void *stream)
 {
+    return urn_gconv_bwd_dw_strided(x, xf_scale, xf_shift, dy, cout, tbl, ld, K, n_out, cin, cout, dw, stream);
+}
+
+extern "C" int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, const float *xf_shift, const float *dy,
+                                        int64_t ld_dy, const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin,
+                                        int cout, float *dw, void *stream)
+{
+    URN_CHECK_ARG(ld_dy >= cout && ld_dy % 4 == 0, "ld_dy smaller than the row or not a multiple of 4");
     if (n_out <= 0) return URN_OK;
     URN_CHECK_ARG(x && dy && tbl && dw, "null pointer");
     URN_CHECK_ARG(K > 0 && cin > 0 && cout > 0 && ld >= n_out, "bad shape");
     URN_CHECK_ARG((xf_scale == nullptr) == (xf_shift == nullptr), "scale and shift go together");
     hipStream_t st = (hipStream_t)stream;
+    if (ld_dy != cout && (g_dw_kernel != 2 || (cin % 16) || (cout % 16))) {
+        urn_set_error("urn_gconv_bwd_dw_strided: a strided dy needs k_gconv_dw2 (channel counts that are multiples of 16)");
+        return URN_EUNSUPPORTED;
+    }
     if ((cin % 16) || (cout % 16)) {
         if (xf_scale) { urn_set_error("urn_gconv_bwd_dw_ex: input transform needs channel counts that are multiples of 16"); return URN_EUNSUPPORTED; }
         int chunks = (int)((n_out + 255) / 256);
@@ -518,11 +530,11 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
 #define URN_DW2P(Sv, XFv, KTv)                                                                                                       \
         do {                                                                                                                         \
             if (prec == 1) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 1>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, \
-                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                             \
+                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy);              \
             else if (prec == 2) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 2>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, \
-                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                   \
+                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy);    \
             else hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 0>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
-                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw);                                                 \
+                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy);                                  \
         } while (0)
 #define URN_DW2K(Sv, KTv)                                                                                                            \
         if (xf_scale) URN_DW2P(Sv, 1, KTv);                                                                                          \

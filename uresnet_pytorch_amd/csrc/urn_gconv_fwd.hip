@@ -376,6 +376,10 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     a.part = u->part; a.e_x = u->e_x; a.e_scale = u->e_scale; a.e_shift = u->e_shift; a.e_mean = u->e_mean;
     a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg;
     a.prec = u->precision > 0 ? u->precision - 1 : g_opt_precision;   // 0 fp32, 1 bf16, 2 fp16
+    a.ldx = u->ldx > 0 ? (long)u->ldx : (long)u->cin;
+    a.ldy = u->ldy > 0 ? (long)u->ldy : (long)u->cout;
+    const bool strided = a.ldx != u->cin || a.ldy != u->cout;
+    URN_CHECK_ARG(a.ldx >= u->cin && a.ldy >= u->cout && a.ldx % 4 == 0, "ldx / ldy smaller than the row, or ldx not a multiple of 4");
     // finalize requested?  In-kernel (last workgroup) only on request: measured on MI355X the tail work (every
     // workgroup drains its stores and takes a ticket, the last one reduces the slab while the chip idles) costs
     // more than the separate finalize launch it saves (6.58 vs 6.14 ms per cfg3 step), so the default is launches.
@@ -407,7 +411,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_GCONV, st);
     bool ok = false;
-    if ((g_opt_kernel == 6 && !in_kernel) || sums_mode || a.prec) {
+    if ((g_opt_kernel == 6 && !in_kernel) || sums_mode || a.prec || strided) {
         const int np6 = urn_gconv_tile_launch(a, ks, u->n_out, st);
         if (np6 > 0) {
             if (prof) urn_prof_end(st);
@@ -416,6 +420,11 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
             URN_LAUNCH_CHECK();
             if (want_fin) return finalize_launches(u, np, stream);
             return URN_OK;
+        }
+        if (strided) {
+            if (prof) urn_prof_end(st);
+            urn_set_error("urn_gconv_fwd_ex: strided x / y need the 2-D tile kernel (cin=%d cout=%d has none)", u->cin, u->cout);
+            return URN_EUNSUPPORTED;
         }
         if (sums_mode) {
             if (prof) urn_prof_end(st);

@@ -33,6 +33,7 @@ struct GArgs {
     long xs_n;
     const float *xs_gamma, *xs_beta;
     float *xs_mean, *xs_invstd, *xs_scale, *xs_shift, *xs_rm, *xs_rv;
+    long ldx, ldy;   // row strides of x and y in floats (cin / cout unless a tensor is a column block of a wider matrix)
     int prec;  // MFMA operand precision: 0 fp32, 1 bf16, 2 fp16 (urn_gconv_args.precision / option "gconv_precision")
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
             const int e = (A_TOT % T == 0) ? j * T + tid : min(j * T + tid, A_TOT - 1);
             const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
             const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
-            ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * cin + ch * CIN + 4 * c4);
+            ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * g.ldx + ch * CIN + 4 * c4);
         }
         const float *wo = g.wt + ((long)o * cout + tile_col0) * cin + ch * CIN;
 #pragma unroll
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         const int e = (A_TOT % T == 0) ? j * T + tid : min(j * T + tid, A_TOT - 1);
         const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
         const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
-        ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * cin + ch * CIN + 4 * c4);
+        ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * g.ldx + ch * CIN + 4 * c4);
     };
     auto piece_fetch_b = [&](int t, int ch, auto slot, auto jj) {
         constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
                 s0 += (double)v;
                 s1 += (double)v * xh;
             }
-            g.y[off] = v;
+            g.y[row * g.ldy + col] = v;   // ldy > cout: the output is a column block of a wider matrix (channel concat)
         }
     }
     if (g.epi == 0) return;

@@ -307,13 +307,14 @@ struct urn_net {
         b.stamp = fwd_stamp;
         b.mean = arena.f32(b.c); b.invstd = arena.f32(b.c); b.scale = arena.f32(b.c); b.shift = arena.f32(b.c);
     }
+    // dst / ld_dst: write the output as a column block of a wider matrix (the up-branch half of a channel concat)
     Act conv_f(ConvP &c, const Act &in, BNP *xf, const int32_t *tbl, int64_t n_out, const float *res, Cons c0,
-               Cons c1 = Cons())
+               Cons c1 = Cons(), float *dst = nullptr, int64_t ld_dst = 0)
     {
         c.x = in.x;
         Act y;
         y.n = n_out; y.c = c.cout;
-        y.x = arena.f32(n_out * c.cout);
+        y.x = dst ? dst : arena.f32(n_out * c.cout);
         const bool mfma = (c.cin % 16 == 0) && (c.cout % 16 == 0);
         const bool stats = c0.bn != nullptr;
         const bool acc = sums_mode() && mfma;         // accumulated statistics on the producing side
@@ -336,6 +337,7 @@ struct urn_net {
         memset(&a, 0, sizeof(a));
         a.x = in.x; a.wt = wt_all + c.w; a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
         a.cin = c.cin; a.cout = c.cout; a.res = res; a.y = y.x;
+        a.ldy = dst ? ld_dst : 0;
         a.fin_eps = eps; a.fin_momentum = momentum;
         if (xs) {
             a.xs_slots = SUM_SLOTS; a.xs_n = in.n;
@@ -383,7 +385,7 @@ struct urn_net {
     // Weight gradients go to the side stream behind a fork (event record on the main stream, wait on the side stream).
     // They can be queued and forked in groups (g_dw_group > 1) -- measured slower: the later a weight gradient
     // starts, the less of it overlaps with the dX chain -- so the default is one fork per convolution.
-    struct DwJob { ConvP *c; const BNP *xf; const float *dy; const int32_t *tbl_f; int64_t n_out; };
+    struct DwJob { ConvP *c; const BNP *xf; const float *dy; const int32_t *tbl_f; int64_t n_out; int64_t ld_dy; };
     std::vector<DwJob> dw_queue;
     void dw_flush()
     {
@@ -397,18 +399,20 @@ struct urn_net {
             }
         }
         for (const DwJob &j : dw_queue)
-            check(urn_gconv_bwd_dw_ex(j.c->x, j.xf ? j.xf->scale : nullptr, j.xf ? j.xf->shift : nullptr, j.dy, j.tbl_f, geo.ld,
-                                      j.c->K, j.n_out, j.c->cin, j.c->cout, grads + j.c->w, ws));
+            check(urn_gconv_bwd_dw_strided(j.c->x, j.xf ? j.xf->scale : nullptr, j.xf ? j.xf->shift : nullptr, j.dy,
+                                           j.ld_dy > 0 ? j.ld_dy : j.c->cout, j.tbl_f, geo.ld, j.c->K, j.n_out, j.c->cin, j.c->cout,
+                                           grads + j.c->w, ws));
         dw_queue.clear();
     }
-    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out)
+    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out, int64_t ld_dy = 0)
     {
-        dw_queue.push_back(DwJob{&c, xf, dy, tbl_f, n_out});
+        dw_queue.push_back(DwJob{&c, xf, dy, tbl_f, n_out, ld_dy});
         if ((int)dw_queue.size() >= g_dw_group) dw_flush();
     }
     // backward of conv(BNReLU_b(x)): returns d/dx (raw input of the BatchNorm), adds `extra` when given
+    // ld_dy / ld_extra: dy / extra are column blocks of a wider matrix (the halves of a concat's gradient); 0 = dense
     float *conv_b_fused(ConvP &c, BNP &b, const float *dy, const int32_t *tbl_f, const int32_t *tbl_b, int flip_b,
-                        int64_t n_out, int64_t n_in, const float *extra)
+                        int64_t n_out, int64_t n_in, const float *extra, int64_t ld_dy = 0, int64_t ld_extra = 0)
     {
         float *g = arena.f32(n_in * c.cin);
         const bool acc = sums_mode();
@@ -416,18 +420,18 @@ struct urn_net {
         float *coef = acc ? nullptr : arena.f32(2 * (int64_t)c.cin);
         float *dx = arena.f32(n_in * c.cin);
         if (live()) {
-            dw_launch(c, &b, dy, tbl_f, n_out);
+            dw_launch(c, &b, dy, tbl_f, n_out, ld_dy);
             urn_gconv_args a;
             memset(&a, 0, sizeof(a));
             a.x = dy; a.wt = params + c.w; a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
-            a.cin = c.cout; a.cout = c.cin; a.y = g;
+            a.cin = c.cout; a.cout = c.cin; a.y = g; a.ldx = ld_dy;
             a.epilogue = 2; a.part = part;
             a.e_x = b.x; a.e_scale = b.scale; a.e_shift = b.shift; a.e_mean = b.mean; a.e_invstd = b.invstd;
             int n_part = 0;
             if (acc) {
                 a.part_slots = SUM_SLOTS;
                 check(urn_gconv_fwd_ex(&a, &n_part, st));
-                check(urn_bn_bwd_apply_sums(b.x, g, extra, n_in, c.cin, params + b.w, b.mean, b.invstd, part, SUM_SLOTS,
+                check(urn_bn_bwd_apply_sums(b.x, g, extra, ld_extra, n_in, c.cin, params + b.w, b.mean, b.invstd, part, SUM_SLOTS,
                                             grads + b.w, grads + b.b, dx, st));
             } else {
                 a.sync_word = sync_word; a.fin_n = n_in;
@@ -472,14 +476,18 @@ struct urn_net {
             t = u_f(*lv.sub, t, l + 1, c_up);
             lv.bn_u.x = t.x;
             Cons c_cat; c_cat.bn = &lv.post[0].bn1; c_cat.coff = P;
-            Act z = conv_f(lv.up, t, &lv.bn_u, geo.up[l], n, nullptr, c_cat);
             Act cat;
             cat.n = n; cat.c = 2 * P;
-            cat.st = x.st; cat.st2 = z.st; cat.c0 = P;   // statistics of the two halves come from their producers
             cat.x = arena.f32(n * 2 * P);
+            // channel concat [skip | up-branch]: the up-conv writes its half in place (row stride 2P) when the kernel
+            // supports it (accumulated-statistics mode = 2-D tile kernel); the skip half is one 2-D copy
+            const bool in_place = sums_mode();
+            Act z = conv_f(lv.up, t, &lv.bn_u, geo.up[l], n, nullptr, c_cat, Cons(), in_place ? cat.x + P : nullptr, 2 * P);
+            cat.st = x.st; cat.st2 = z.st; cat.c0 = P;   // statistics of the two halves come from their producers
             if (live()) {
                 check(hipMemcpy2DAsync(cat.x, 2 * P * 4, x.x, P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
-                check(hipMemcpy2DAsync(cat.x + P, 2 * P * 4, z.x, P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
+                if (!in_place)
+                    check(hipMemcpy2DAsync(cat.x + P, 2 * P * 4, z.x, P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
             }
             lv.post[0].bn1.x = cat.x;
             x = cat;
@@ -508,14 +516,24 @@ struct urn_net {
             const int64_t n = geo.n[l], nc_ = geo.n[l + 1];
             const int P = planes[l];
             for (int i = (int)lv.post.size() - 1; i >= 0; --i) dy = block_b(lv.post[i], dy, l);
-            float *dskip = arena.f32(n * P), *dz = arena.f32(n * P);
-            if (live()) {
-                check(hipMemcpy2DAsync(dskip, P * 4, dy, 2 * P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
-                check(hipMemcpy2DAsync(dz, P * 4, dy + P, 2 * P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
+            // dy is (n, 2P) = [gradient of the skip half | gradient of the up-branch half]: both halves are consumed in
+            // place through row strides (accumulated-statistics mode); otherwise split by two 2-D copies
+            float *d;
+            if (sums_mode()) {
+                const float *dcat = dy;
+                d = conv_b_fused(lv.up, lv.bn_u, dcat + P, geo.up[l], geo.chd[l], 0, n, nc_, nullptr, 2 * P, 0);
+                d = u_b(*lv.sub, d, l + 1);
+                dy = conv_b_fused(lv.down, lv.bn_d, d, geo.chd[l], geo.up[l], 0, nc_, n, dcat, 0, 2 * P);   // + skip-path gradient
+            } else {
+                float *dskip = arena.f32(n * P), *dz = arena.f32(n * P);
+                if (live()) {
+                    check(hipMemcpy2DAsync(dskip, P * 4, dy, 2 * P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
+                    check(hipMemcpy2DAsync(dz, P * 4, dy + P, 2 * P * 4, P * 4, n, hipMemcpyDeviceToDevice, st) == hipSuccess ? URN_OK : URN_EHIP);
+                }
+                d = conv_b_fused(lv.up, lv.bn_u, dz, geo.up[l], geo.chd[l], 0, n, nc_, nullptr);
+                d = u_b(*lv.sub, d, l + 1);
+                dy = conv_b_fused(lv.down, lv.bn_d, d, geo.chd[l], geo.up[l], 0, nc_, n, dskip);   // + skip-path gradient
             }
-            float *d = conv_b_fused(lv.up, lv.bn_u, dz, geo.up[l], geo.chd[l], 0, n, nc_, nullptr);
-            d = u_b(*lv.sub, d, l + 1);
-            dy = conv_b_fused(lv.down, lv.bn_d, d, geo.chd[l], geo.up[l], 0, nc_, n, dskip);   // + skip-path gradient
         }
         for (int i = (int)lv.pre.size() - 1; i >= 0; --i) dy = block_b(lv.pre[i], dy, l);
         return dy;

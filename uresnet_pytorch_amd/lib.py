@@ -34,7 +34,8 @@ class GConvArgs(ctypes.Structure):
                 ('xs_ld', ctypes.c_int * 2), ('xs_sums', ctypes.c_void_p * 2), ('xs_n', ctypes.c_int64),
                 ('xs_gamma', ctypes.c_void_p), ('xs_beta', ctypes.c_void_p), ('xs_mean', ctypes.c_void_p),
                 ('xs_invstd', ctypes.c_void_p), ('xs_scale', ctypes.c_void_p), ('xs_shift', ctypes.c_void_p),
-                ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p), ('precision', ctypes.c_int)]
+                ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p), ('precision', ctypes.c_int),
+                ('ldx', ctypes.c_int64), ('ldy', ctypes.c_int64)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/uresnet_hip.h
@@ -81,8 +82,10 @@ SIGNATURES = {
     'urn_bn_finalize_bwd': (c_int, [c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_bn_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
-    'urn_bn_bwd_apply_sums': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p,
+    'urn_bn_bwd_apply_sums': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_gconv_bwd_dw_strided': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_i64,
+                                         c_int, c_int, c_void_p, c_void_p]),
     'urn_adam_flat': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_double, c_double, c_double, c_double,
                               c_double, c_i64, c_void_p]),
     'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
