@@ -419,7 +419,6 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         for (int i = 0; i < 4; ++i) {
             const long row = row_base + q * 4 + i;
             if (row >= n_out) continue;
-            const long off = row * cout + col;
             float v = acc[i] + acc2[i];
             if (g.res && !STAMP) v += pre_res[i];
             if (g.epi == 1) {
