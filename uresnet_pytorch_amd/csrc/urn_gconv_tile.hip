@@ -534,6 +534,13 @@ int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
             return (int)bx;
         }
     }
+    if ((a.dbg & 32) && KS == 1 && a.cout == 16) {   // ... and of the 16 -> 16 shape (level 0)
+        if constexpr (KS == 1) {
+            const long bx = (n_out + 63) / 64;
+            hipLaunchKernelGGL((k_gconv_tile<1, 4, 1, 1, 1>), dim3((unsigned)bx, 1), dim3(256), 0, st, a);
+            return (int)bx;
+        }
+    }
     if ((a.dbg >> 8) && ((KS == 4 && a.cout == 64) || (KS == 1 && a.cout == 16))) {   // timing-only ablations of two shapes
         constexpr int PRB = KS == 4 ? 2 : 4, PCB = KS == 4 ? 4 : 1;
         if constexpr (KS == 4 || KS == 1) {
