@@ -379,6 +379,8 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     a.ldx = u->ldx > 0 ? (long)u->ldx : (long)u->cin;
     a.ldy = u->ldy > 0 ? (long)u->ldy : (long)u->cout;
     const bool strided = a.ldx != u->cin || a.ldy != u->cout;
+    // the interleaved tile kernel addresses gathered rows with 32-bit byte offsets: rows (< ld) * ldx * 4 must fit
+    const bool off32_ok = (double)u->ld * (double)a.ldx * 4.0 < 4294967296.0 && (double)u->K * u->cin * u->cout * 4.0 < 2147483648.0;
     URN_CHECK_ARG(a.ldx >= u->cin && a.ldy >= u->cout && a.ldx % 4 == 0, "ldx / ldy smaller than the row, or ldx not a multiple of 4");
     // finalize requested?  In-kernel (last workgroup) only on request: measured on MI355X the tail work (every
     // workgroup drains its stores and takes a ticket, the last one reduces the slab while the chip idles) costs
@@ -411,7 +413,12 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_GCONV, st);
     bool ok = false;
-    if ((g_opt_kernel == 6 && !in_kernel) || sums_mode || a.prec || strided) {
+    if (!off32_ok && (sums_mode || strided)) {
+        urn_set_error("urn_gconv_fwd_ex: accumulated statistics / strided operands need the 2-D tile kernel, whose 32-bit row offsets "
+                      "do not cover ld=%ld x ldx=%ld", (long)u->ld, a.ldx);
+        return URN_EUNSUPPORTED;
+    }
+    if (off32_ok && ((g_opt_kernel == 6 && !in_kernel) || sums_mode || a.prec || strided)) {
         const int np6 = urn_gconv_tile_launch(a, ks, u->n_out, st);
         if (np6 > 0) {
             if (prof) urn_prof_end(st);

@@ -230,17 +230,20 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         else t_run = -1;
     };
     int rt[D], rc[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        take(rt[i], rc[i]);
-        fetch(rt[i] < 0 ? 0 : rt[i], rc[i], i);   // unconditional (a dummy step past the end): see step()
-    }
-    park(rt[0] < 0 ? 0 : rt[0], rc[0], 0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
     int buf = 0;
-    int ct = rt[0];   // the step whose operands are in LDS image `buf`
+    int ct = -1;   // the step whose operands are in LDS image `buf`
+    if constexpr (IL == 0) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            take(rt[i], rc[i]);
+            fetch(rt[i] < 0 ? 0 : rt[i], rc[i], i);   // unconditional (a dummy step past the end): see step()
+        }
+        park(rt[0] < 0 ? 0 : rt[0], rc[0], 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ct = rt[0];
+    }
     unsigned long long st_fetch = 0, st_mfma = 0, st_park = 0, st_bar = 0, st_n = 0;   // STAMP build only
 #define URN_STAMP(v)                                                                          \
     unsigned long long v = 0;                                                                 \
@@ -292,41 +295,71 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     // zero-fill plus the LDS writes of step +1, fragment reads of this step) is cut into pieces and placed between
     // the MFMAs of this step, in one basic block: the matrix pipe of a SIMD is then fed while its waves do the
     // bookkeeping, instead of all waves of the workgroup alternating between a bookkeeping phase and an MFMA phase.
+    // Per-thread constants of the pieces: the offset loop of a narrow layer is bound by instruction issue (a wave64 VALU
+    // instruction occupies the 16-lane SIMD for four cycles, and the waves of up to three workgroups share it), so
+    // everything that does not change from step to step is computed once: LDS positions, 32-bit byte offsets into
+    // the rows and into the weight tile (global loads in scalar-base + 32-bit-offset form), the folded BatchNorm
+    // affine of the thread's four channels, and the validity of a gathered row travels with it in the ring.
+    int a_idx[A_F4];                       // position of the piece's row in s_idx (offset 0)
+    unsigned a_off[A_F4], b_off[B_F4];     // byte offsets inside a row / inside the weight tile of an offset
+    float *a_dst[A_F4], *b_dst[B_F4];      // LDS row of the piece in image 0
+    int a_c4[A_F4], b_c4[B_F4];
+    f32x4 a_sc[A_F4], a_sh[A_F4];
+    bool rv[D][A_F4];
+    const bool xf_regs = nch == 1;         // one chunk: the affine of the thread's channels stays in registers
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) {
+        const int e = (A_TOT % T == 0) ? j * T + tid : min(j * T + tid, A_TOT - 1);   // duplicates rewrite the same value
+        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
+        a_idx[j] = (row >> 4) * (28 * 16) + (row & 15);
+        a_off[j] = (unsigned)c4 * 16u;
+        a_dst[j] = &s_a[0][row][0];
+        a_c4[j] = c4;
+        if (IL == 2 && xf_regs) { a_sc[j] = *(const f32x4 *)&s_xf[0][4 * c4]; a_sh[j] = *(const f32x4 *)&s_xf[1][4 * c4]; }
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; ++j) {
+        const int e = (B_TOT % T == 0) ? j * T + tid : min(j * T + tid, B_TOT - 1);
+        const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
+        b_off[j] = (unsigned)(col * cin + 4 * c4) * 4u;
+        b_dst[j] = &s_b[0][col][0];
+        b_c4[j] = c4;
+    }
+    const unsigned ldx4 = (unsigned)g.ldx * 4u;                                   // host checks rows * ldx * 4 < 2^32
+    const char *const wt_tile = (const char *)(g.wt + (long)tile_col0 * cin);    // this workgroup's columns, offset 0
+    const int wstride = cout * cin;                                             // floats per offset (< 2^31 / 27)
+    constexpr int A_IMG = RB * 16 * LDS_LD, B_IMG = CB * 16 * LDS_LD;           // floats per LDS image
     auto piece_fetch_a = [&](int t, int ch, auto slot, auto jj) {
         constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
-        const int e = (A_TOT % T == 0) ? j * T + tid : min(j * T + tid, A_TOT - 1);
-        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
-        const int idx = s_idx[row >> 4][t * 16 + (row & 15)];
-        ra[gi][j] = *(const f32x4 *)(g.x + (long)(idx < 0 ? 0 : idx) * g.ldx + ch * CIN + 4 * c4);
+        const int idx = (&s_idx[0][0])[a_idx[j] + t * 16];
+        rv[gi][j] = idx >= 0;
+        const unsigned off = (unsigned)max(idx, 0) * ldx4 + a_off[j];
+        ra[gi][j] = *(const f32x4 *)((const char *)(g.x + ch * CIN) + off);
     };
     auto piece_fetch_b = [&](int t, int ch, auto slot, auto jj) {
         constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
         const int o = g.flip ? (K - 1 - t) : t;
-        const float *wo = g.wt + ((long)o * cout + tile_col0) * cin + ch * CIN;
-        const int e = (B_TOT % T == 0) ? j * T + tid : min(j * T + tid, B_TOT - 1);
-        const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
-        rb_[gi][j] = *(const f32x4 *)(wo + (long)col * cin + 4 * c4);
+        const char *wo = wt_tile + (long)(o * wstride + ch * CIN) * 4;
+        rb_[gi][j] = *(const f32x4 *)(wo + b_off[j]);
     };
     auto piece_park_a = [&](int t, int ch, int pbuf, auto slot, auto jj) {
         constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
-        const int e = (A_TOT % T == 0) ? j * T + tid : min(j * T + tid, A_TOT - 1);   // duplicates rewrite the same value
-        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
-        const bool have = s_idx[row >> 4][t * 16 + (row & 15)] >= 0;
         f32x4 v = ra[gi][j];
         if constexpr (IL == 2) {
-            const f32x4 sc = *(const f32x4 *)&s_xf[0][ch * CIN + 4 * c4], sh = *(const f32x4 *)&s_xf[1][ch * CIN + 4 * c4];
+            f32x4 sc, sh;
+            if (xf_regs) { sc = a_sc[j]; sh = a_sh[j]; }
+            else { sc = *(const f32x4 *)&s_xf[0][ch * CIN + 4 * a_c4[j]]; sh = *(const f32x4 *)&s_xf[1][ch * CIN + 4 * a_c4[j]]; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
         }
+        const bool have = rv[gi][j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = have ? v[k] : 0.f;
-        lds_store(&s_a[pbuf][row][0], c4, v);
+        lds_store(a_dst[j] + pbuf * A_IMG, a_c4[j], v);
     };
     auto piece_park_b = [&](int pbuf, auto slot, auto jj) {
         constexpr int gi = decltype(slot)::value, j = decltype(jj)::value;
-        const int e = (B_TOT % T == 0) ? j * T + tid : min(j * T + tid, B_TOT - 1);
-        const int col = e / (CIN / 4), c4 = e - col * (CIN / 4);
-        lds_store(&s_b[pbuf][col][0], c4, rb_[gi][j]);
+        lds_store(b_dst[j] + pbuf * B_IMG, b_c4[j], rb_[gi][j]);
     };
     auto step_il = [&](auto slot) {
         constexpr int u = decltype(slot)::value;
@@ -392,6 +425,20 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
         buf ^= 1;
     };
     if constexpr (IL != 0 && D == 2) {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        take(rt[0], rc[0]);
+        static_for<0, A_F4>([&](auto jj) { piece_fetch_a(max(rt[0], 0), rc[0], I0(), jj); });
+        static_for<0, B_F4>([&](auto jj) { piece_fetch_b(max(rt[0], 0), rc[0], I0(), jj); });
+        take(rt[1], rc[1]);
+        static_for<0, A_F4>([&](auto jj) { piece_fetch_a(max(rt[1], 0), rc[1], I1(), jj); });
+        static_for<0, B_F4>([&](auto jj) { piece_fetch_b(max(rt[1], 0), rc[1], I1(), jj); });
+        static_for<0, A_F4>([&](auto jj) { piece_park_a(max(rt[0], 0), rc[0], 0, I0(), jj); });
+        static_for<0, B_F4>([&](auto jj) { piece_park_b(0, I0(), jj); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ct = rt[0];
         while (ct >= 0) {
             step_il(std::integral_constant<int, 0>());
             if (ct < 0) break;
