@@ -516,8 +516,8 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 #define URN_TILE_GLOBAL(decl, init) extern decl
 #endif
 URN_TILE_GLOBAL(int g_tile_depth, 0);   // kept for the option table; no effect
-URN_TILE_GLOBAL(int g_tile_il, 1);            // interleaved step for KS >= URN_IL_MIN_KS (urn_set_option("tile_il", 0) = plain step)
-#define URN_IL_MIN_KS 2
+URN_TILE_GLOBAL(int g_tile_il, 1);            // interleaved step (urn_set_option("tile_il", 0) = plain step)
+URN_TILE_GLOBAL(int g_tile_il_min_ks, 1);     // narrowest channel step that takes the interleaved variant (urn_set_option "tile_il_min_ks")
 
 template <int KS, int RB, int CB>
 static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
@@ -537,8 +537,8 @@ static int launch_tile2(const GArgs &a, long n_out, hipStream_t st)
             return (int)bx;
         }
     }
-    if constexpr (KS >= URN_IL_MIN_KS) {
-        if (g_tile_il) {
+    {
+        if (g_tile_il && KS >= g_tile_il_min_ks) {
             const bool xfm = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
             if (xfm) hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2, 0, 0, 2>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_gconv_tile<KS, RB, CB, 2, 0, 0, 1>), grid, block, 0, st, a);
