@@ -7,11 +7,9 @@ from uresnet_pytorch_amd import parallel
 from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
 from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
 dev = torch.device('cuda:0')
-from uresnet_pytorch_amd import lib as _l
-if len(sys.argv) > 5:
-    _l.load().urn_set_option(b'gconv_precision', int(sys.argv[5]))   # 0 fp32, 1 bf16, 2 fp16
+PREC = ('fp32', 'bf16', 'fp16')[int(sys.argv[5])] if len(sys.argv) > 5 else 'fp32'   # MFMA operand precision (flags -prec)
 S, n, m, Lv = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=5)
+flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=5, PRECISION=PREC)
 blob = make_sparse_blob([0], S, n)
 data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
 torch.manual_seed(0)

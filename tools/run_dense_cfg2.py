@@ -11,10 +11,8 @@ from uresnet_pytorch_amd.models import DenseUResNet, DenseSegmentationLoss
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 uns = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device('cuda:0')
-from uresnet_pytorch_amd import lib as _l
-if len(sys.argv) > 3:
-    _l.load().urn_set_option(b'gconv_precision', int(sys.argv[3]))   # 0 fp32, 1 bf16, 2 fp16
-flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=uns, SPATIAL_SIZE=S, NUM_CLASS=5, BN_MOMENTUM=0.9)
+PREC = ('fp32', 'bf16', 'fp16')[int(sys.argv[3])] if len(sys.argv) > 3 else 'fp32'   # MFMA operand precision (flags -prec)
+flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=uns, SPATIAL_SIZE=S, NUM_CLASS=5, BN_MOMENTUM=0.9, PRECISION=PREC)
 torch.manual_seed(0)
 net = DenseUResNet(flags).to(dev).train()
 crit = DenseSegmentationLoss(flags)
