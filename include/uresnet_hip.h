@@ -287,7 +287,17 @@ int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stre
  * kind 0 = gather-conv forward/input-gradient kernel, 1 = weight-gradient kernel.
  * urn_prof_enable resets the records; urn_prof_read waits for the recorded events. */
 int urn_prof_enable(int on);
-/* tuning knobs for A/B measurements: "gconv_pipe" (0/1), "gconv_min_waves" */
+/* Library-wide options.  Behaviour:
+ *   "gconv_precision" 0 fp32 (default) | 1 bf16 | 2 fp16 -- MFMA operand precision of calls that do not set
+ *                     urn_gconv_args.precision, and of the weight gradient.
+ * Tuning / A-B switches (defaults are the measured optima; tools/ use them):
+ *   "gconv_kernel" 6 2-D tile (default) | 4 64x16 LDS tile | 5 LDS-DMA ring | 3 register gather;
+ *   "tile_il" 1/0 interleaved offset step, "tile_il_min_ks" narrowest channel step that takes it;
+ *   "tile_rb" / "tile_cb" / "tile_kc" force the workgroup tile / channels per step (0 = automatic);
+ *   "dw_kernel" 2/1, "dw_blocks" workgroup target, "dw_split" 0 never | 1 automatic | 2 always, "dw_group"
+ *   weight gradients per fork to the side stream; "fin_in_kernel" finalize BatchNorm statistics by the last
+ *   workgroup (slab mode); "gconv_dbg" timing-only ablation / probe mask (results are garbage with most bits);
+ *   "gconv_pipe", "gconv_min_waves", "gconv_lds_min_wgs" knobs of the older kernels. */
 int urn_set_option(const char *key, int64_t value);
 int urn_prof_read(int kind, double *total_ms, int64_t *launches);
 

@@ -35,7 +35,7 @@ class UResNet(torch.nn.Module):
         # fast path: the whole sparseModel inside the C++ executor (same kernels, one autograd node);
         # m must be a multiple of 16 (MFMA tiles).  use_executor=False keeps the per-layer path.
         self.use_executor = (dimension == 3 and m % 16 == 0)
-        self.executor_flags = 0     # lib URN_NET_UNFUSED (1) / URN_NET_SINGLE_STREAM (2): debug and A/B switches
+        self.executor_flags = 0     # lib URN_NET_UNFUSED (1) / URN_NET_SINGLE_STREAM (2) / URN_NET_SLAB_STATS (4): debug and A/B switches
         self._executor = None
 
     def _trunk(self, coords, features):

@@ -39,7 +39,7 @@ class TrunkExecutor:
     def __init__(self, sparse_model, m, num_levels, reps, num_class):
         self.model = sparse_model
         self.cfg = (m, num_levels, reps, num_class)
-        self.flags = 0            # URN_NET_UNFUSED = 1, URN_NET_SINGLE_STREAM = 2 (debug / A-B switches)
+        self.flags = 0            # URN_NET_UNFUSED = 1, URN_NET_SINGLE_STREAM = 2, URN_NET_SLAB_STATS = 4 (debug / A-B switches)
         self.handle = None
         self.slots = []
         self.flat = None
