@@ -605,3 +605,30 @@ def test_reduced_precision_operands(dev, prec, tol_op, tol_net):
         assert rel(got, want) < 8 * tol_net, rel(got, want)
     finally:
         L_.set_precision('fp32')
+
+
+def test_network_cfg5_size_modes_agree(dev):
+    """BASELINE configs[4] topology (-ss 768, 200k voxels, -uf 32 -uns 7: channels 32..224, inputs up to 448 wide walked
+    in chunks) in fp32: too large for the oracle in seconds, so the check is a size-independent property -- the two
+    statistics modes of the executor (accumulated sums vs per-workgroup slabs + finalize launches, different
+    kernels' epilogues and prologues, different launch sequences) agree on logits, loss and gradients."""
+    from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
+    S, m, Lv, nc = 768, 32, 7, 5
+    blob = make_sparse_blob([3], S, 200000)
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=nc)
+    data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
+    res = []
+    for fl in (0, 4):
+        torch.manual_seed(0)
+        net = SparseUResNet(flags).to(dev).train()
+        net.executor_flags = fl
+        out = net(data)
+        loss, acc = SparseSegmentationLoss(flags)(out, [data], [label], None)
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        assert torch.isfinite(out[0]).all() and torch.isfinite(g).all()
+        res.append((out[0].detach().cpu().numpy(), float(loss), g.cpu().numpy()))
+        del net, out, loss
+    assert rel(res[0][0], res[1][0]) < 1e-5
+    assert abs(res[0][1] - res[1][1]) < 1e-5 * abs(res[1][1])
+    assert rel(res[0][2], res[1][2]) < 1e-3      # ReLU-mask flips between the two summation orders (see cfg3 test)
