@@ -154,3 +154,35 @@ def test_dense_gpu_route_bf16_operands():
         assert all(torch.isfinite(p.grad).all() for p in gpu.parameters() if p.grad is not None)
     finally:
         L_.set_precision('fp32')
+
+
+@pytest.mark.gpu
+def test_dense_cfg2_full_size():
+    """BASELINE configs[1] at full size (-dd 3 -ss 128 -nc 5 -uf 16 -uns 5, 50.3 M parameters, one event): too large for
+    the CPU route in seconds, so the checks are properties: the parameter count of SURVEY App. B, finite logits and
+    gradients, unused shortcut convs without gradient, and bf16 operands within bf16 tolerance of fp32 operands."""
+    from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+    from uresnet_pytorch_amd import lib as L_
+    dev = torch.device('cuda:0')
+    S = 128
+    mk = lambda prec: SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=5, SPATIAL_SIZE=S, NUM_CLASS=5,
+                                      BN_MOMENTUM=0.9, PRECISION=prec)
+    blob = make_dense_blob([0], S, 3)
+    x = torch.from_numpy(blob['data']).to(dev); lab = torch.from_numpy(blob['label']).to(dev)
+    try:
+        torch.manual_seed(0)
+        net = DenseUResNet(mk('fp32')).to(dev).train()
+        assert sum(p.numel() for p in net.parameters()) == 50320383
+        out = net(x)
+        loss, acc = DenseSegmentationLoss(mk('fp32'))(list(out), list(x), list(lab), None)
+        loss.backward()
+        assert out.shape == (1, 5, S, S, S) and torch.isfinite(out).all() and torch.isfinite(loss)
+        with_grad = [k for k, p in net.named_parameters() if p.grad is not None]
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+        assert not any('resnet2.shortcut' in k for k in with_grad)      # registered but never executed (reference :36-46,72-73)
+        ref = out.detach().float().cpu().numpy()
+        net._flags = mk('bf16')
+        out16 = net(x)
+        assert 1e-5 < rel(out16.detach().cpu().numpy(), ref) < 5e-2
+    finally:
+        L_.set_precision('fp32')
