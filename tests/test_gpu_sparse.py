@@ -632,3 +632,27 @@ def test_network_cfg5_size_modes_agree(dev):
     assert rel(res[0][0], res[1][0]) < 1e-5
     assert abs(res[0][1] - res[1][1]) < 1e-5 * abs(res[1][1])
     assert rel(res[0][2], res[1][2]) < 1e-3      # ReLU-mask flips between the two summation orders (see cfg3 test)
+
+
+def test_executor_eval_mode_matches_per_layer_path(dev):
+    """Inference (model.eval(), no autograd: trainval.forward with TRAIN=False) through the executor -- BatchNorm folded
+    into the convolutions with the RUNNING statistics -- against the per-layer eval path."""
+    S, m, L, nc = 64, 16, 4, 5
+    blob = make_sparse_blob([5, 6], S, 3000)
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=L, SPATIAL_SIZE=S, NUM_CLASS=nc)
+    P = orc.init_params(m, L, nc, seed=2)
+    data = torch.from_numpy(blob['data']).to(dev)
+    net = make_model(flags, P, dev)
+    net.train()
+    for _ in range(2):      # two training forwards move the running statistics away from their initial values
+        net(data)
+    net.eval()
+    running_before = {k: v.clone() for k, v in net.state_dict().items() if 'running' in k}
+    with torch.no_grad():
+        out_ex = net(data)[0]
+        net.use_executor = False
+        out_pl = net(data)[0]
+    assert rel(out_ex.cpu().numpy(), out_pl.cpu().numpy()) < 1e-5
+    for k, v in net.state_dict().items():
+        if 'running' in k:
+            assert torch.equal(v, running_before[k]), k      # eval does not touch the running statistics

@@ -316,7 +316,7 @@ struct urn_net {
         y.n = n_out; y.c = c.cout;
         y.x = dst ? dst : arena.f32(n_out * c.cout);
         const bool mfma = (c.cin % 16 == 0) && (c.cout % 16 == 0);
-        const bool stats = c0.bn != nullptr;
+        const bool stats = c0.bn != nullptr && training;   // eval: running statistics, nothing to collect
         const bool acc = sums_mode() && mfma;         // accumulated statistics on the producing side
         const bool xs = xf && in.st.part != nullptr;  // ... and on the consuming side (the input carries its sums)
         double *part = nullptr;
@@ -349,7 +349,7 @@ struct urn_net {
             a.xs_running_mean = running ? running + xf->run : nullptr;
             a.xs_running_var = running ? running + xf->run + xf->c : nullptr;
         } else if (xf) {
-            a.xf_scale = xf->scale; a.xf_shift = xf->shift;
+            a.xf_scale = xf->scale; a.xf_shift = xf->shift;   // from the stem's finalize launch, or from eval_coeffs()
         }
         const Cons cons[2] = {c0, c1};
         if (stats && acc) {
@@ -442,6 +442,17 @@ struct urn_net {
         }
         return dx;
     }
+    // eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (and mean / invstd for the
+    // last BatchNormReLU) of EVERY BatchNorm, one launch; the convolutions then fold them like the batch statistics
+    std::vector<BNP *> all_bns;
+    void collect_bns(ULevel &lv)
+    {
+        for (auto &k : lv.pre) { all_bns.push_back(&k.bn1); all_bns.push_back(&k.bn2); }
+        if (lv.has_sub) { all_bns.push_back(&lv.bn_d); collect_bns(*lv.sub); all_bns.push_back(&lv.bn_u); }
+        for (auto &k : lv.post) { all_bns.push_back(&k.bn1); all_bns.push_back(&k.bn2); }
+    }
+    void eval_coeffs();   // defined below (needs a kernel)
+
     // out0/out1: the BatchNorms that consume this block's output
     Act block_f(Block &k, const Act &x, int l, Cons out0, Cons out1 = Cons())
     {
@@ -556,6 +567,47 @@ float *urn_net::add_into_new(const float *a, const float *b, int64_t count)
     float *o = arena.f32(count);
     if (live() && count > 0) hipLaunchKernelGGL(k_add2, dim3(urn_cdiv((count + 3) / 4, 256)), dim3(256), 0, st, a, b, (long)count, o);
     return o;
+}
+
+#define URN_MAX_BNS 128
+struct BNDesc { long w, b, run, out; int c; };
+struct BNDescs { int n; BNDesc d[URN_MAX_BNS]; };
+
+__global__ void k_bn_eval_coeffs(BNDescs t, const float *__restrict__ params, const float *__restrict__ running, double eps,
+                                 float *__restrict__ coef)
+{
+    const BNDesc d = t.d[blockIdx.x];
+    for (int e = threadIdx.x; e < d.c; e += blockDim.x) {
+        const float mean = running[d.run + e], var = running[d.run + d.c + e];
+        const float is = (float)(1.0 / sqrt((double)var + eps));
+        const float sc = params[d.w + e] * is;
+        coef[d.out + e] = mean;                       // [mean | invstd | scale | shift], c each
+        coef[d.out + d.c + e] = is;
+        coef[d.out + 2 * d.c + e] = sc;
+        coef[d.out + 3 * d.c + e] = fmaf(-mean, sc, params[d.b + e]);
+    }
+}
+
+void urn_net::eval_coeffs()
+{
+    if (all_bns.empty()) { collect_bns(u); all_bns.push_back(&bn_out); }
+    long total = 0;
+    for (BNP *b : all_bns) total += 4L * b->c;
+    float *coef = arena.f32(total);
+    BNDescs t;
+    long off = 0;
+    size_t i = 0;
+    while (i < all_bns.size()) {
+        t.n = 0;
+        for (; i < all_bns.size() && t.n < URN_MAX_BNS; ++i) {
+            BNP *b = all_bns[i];
+            t.d[t.n++] = BNDesc{(long)b->w, (long)b->b, (long)b->run, off, b->c};
+            b->mean = coef + off; b->invstd = coef + off + b->c; b->scale = coef + off + 2 * b->c; b->shift = coef + off + 3 * b->c;
+            b->stamp = fwd_stamp;
+            off += 4L * b->c;
+        }
+        if (live()) hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(t.n), dim3(64), 0, st, t, params, running, eps, coef);
+    }
 }
 
 extern "C" int urn_net_create(int m, int num_levels, int reps, int num_class, double eps, double momentum, int flags,
@@ -683,6 +735,10 @@ static void run_forward(urn_net *net, const float *site_feats)
         // (the ticket word is only used by the in-kernel finalize of the slab-statistics mode)
         if (net->live() && !net->sums_mode()) net->check(hipMemsetAsync(net->sync_word, 0, 256, net->st) == hipSuccess ? URN_OK : URN_EHIP);
         if (net->sums_mode()) net->sums_begin();
+        if (!net->training) {
+            if (!net->running) { urn_set_error("urn_net_forward: eval mode needs the running statistics"); net->check(URN_EINVAL); return; }
+            net->eval_coeffs();
+        }
         Act f;
         f.x = const_cast<float *>(site_feats); f.n = n0; f.c = 1;
         Cons c_first; c_first.bn = &net->u.pre[0].bn1;
@@ -693,7 +749,7 @@ static void run_forward(urn_net *net, const float *site_feats)
         // the last BatchNormReLU feeds the OutputLayer, not a conv: materialise it
         BNP &b = net->bn_out;
         b.x = x.x;
-        if (x.st.part) {   // accumulated statistics: the slab is a partial slab of SUM_SLOTS rows
+        if (x.st.part && net->training) {   // accumulated statistics: the slab is a partial slab of SUM_SLOTS rows
             net->alloc_bn(b);
             if (net->live())
                 net->check(urn_bn_finalize_fwd(x.st.part, x.st.n_part, n0, b.c, x.st.ld, net->eps, net->params + b.w, net->params + b.b,

@@ -51,8 +51,8 @@ class UResNet(torch.nn.Module):
         ex.flatten(c.device, tail=(self.linear.weight, self.linear.bias))
         geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels, defer_sync=True)
         feats = so.input_features(geo, features)
-        ex.prepare(geo, True)
-        return ex.forward(geo, feats, True)
+        ex.prepare(geo, self.training)
+        return ex.forward(geo, feats, self.training)
 
     def forward(self, point_cloud):
         """point_cloud: (N, d+2) rows [x, y, z, batch_id, value]; returns [ (N, NUM_CLASS) ]."""
@@ -60,7 +60,9 @@ class UResNet(torch.nn.Module):
         features = point_cloud[:, -1][:, None].float()
         if coords.is_cuda:
             _lib.set_precision(getattr(self._flags, 'PRECISION', 'fp32'))   # flags -prec: fp32 (default) | bf16 | fp16
-        if self.use_executor and self.training and coords.is_cuda:
+        # the executor serves training steps and (with the running BatchNorm statistics) inference without gradients;
+        # eval mode WITH autograd, hooks and CPU tensors take the per-layer path
+        if self.use_executor and coords.is_cuda and (self.training or not torch.is_grad_enabled()):
             x = self._trunk(coords, features)
         else:
             x = self.sparseModel((coords, features))

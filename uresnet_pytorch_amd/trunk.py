@@ -203,7 +203,7 @@ class TrunkExecutor:
     def forward(self, geo, feats, training):
         """site features -> (n_rows, m) rows in input order.  Recorded for backward when training."""
         need_bwd = bool(training and torch.is_grad_enabled())   # grad mode is off inside Function.forward
-        return _TrunkFunction.apply(feats, self.params[0], self, geo, need_bwd)
+        return _TrunkFunction.apply(feats, self.params[0], self, geo, need_bwd, bool(training))
 
 
 class _TrunkFunction(torch.autograd.Function):
@@ -212,10 +212,9 @@ class _TrunkFunction(torch.autograd.Function):
     buffer directly (the parameters' .grad tensors alias it)."""
 
     @staticmethod
-    def forward(ctx, feats, anchor, ex, geo, need_bwd):
+    def forward(ctx, feats, anchor, ex, geo, need_bwd, training=True):
         L = _l.load()
         Lv = geo.num_levels
-        training = True
         prep = ex._prep if (ex._prep is not None and ex._prep['geo'] is geo and ex._prep['need_bwd'] == need_bwd) else None
         ex._prep = None
         if prep is None:
@@ -243,4 +242,4 @@ class _TrunkFunction(torch.autograd.Function):
         d_rows = d_rows.contiguous()
         _l.check(L.urn_net_backward(ctx.slot.handle, d_rows.data_ptr(), gptr, _l.stream()), 'net_backward')
         ctx.slot.token = None
-        return None, None, None, None, None
+        return None, None, None, None, None, None
