@@ -174,3 +174,13 @@ def test_inference_metrics_against_brute_force():
         if pred[y, x] < nc - 1:
             conf[int(lab[0, y, x]), pred[y, x]] += 1
     assert np.array_equal(r['confusion_matrix'][0], conf) and r['confusion_matrix'][0].shape == (nc - 1, nc - 1)
+
+
+def test_deferred_float_behaves_like_a_float():
+    """utils.DeferredFloat: the accuracy the GPU loss returns -- a device scalar that becomes a python float on first use."""
+    from uresnet_pytorch_amd.utils import DeferredFloat
+    d = DeferredFloat(torch.tensor(0.75))
+    assert abs(d - 0.75) < 1e-7 and d / 3 == 0.25 and 1 + d == 1.75 and d * 2 == 1.5 and 2 - d == 1.25
+    assert float(np.array([d, DeferredFloat(torch.tensor(0.25))]).sum()) == 1.0        # trainval sums per-entry accuracies
+    assert '%.2f' % d == '0.75' and '{:f}'.format(d) == '0.750000' and 0.0 <= d <= 1.0 and d > 0.5 and bool(d)
+    assert d._t is None                                                                 # the device tensor is released after use
