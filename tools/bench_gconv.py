@@ -37,6 +37,9 @@ variants = [('auto', (0, 0, 0))]
 if len(sys.argv) > 1 and sys.argv[1] == 'il':
     variants = [('plain', (0, 0, 0, 0, 0)), ('interleaved', (0, 0, 0, 0, 1))]
     shapes = [(0, 16, 16), (1, 32, 32), (0, 32, 16), (0, 16, 32), (1, 16, 32), (1, 32, 64), (2, 32, 48)] + shapes[2:5]
+if len(sys.argv) > 1 and sys.argv[1] == 'narrow':
+    shapes = [(0, 16, 16), (0, 32, 16), (0, 16, 32), (1, 32, 32), (1, 16, 32), (1, 64, 32), (1, 32, 64)]
+    variants = [('auto', (0, 0, 0))] + [('%dx%d' % (r, c), (r, c, 0)) for r in (1, 2, 4) for c in (1, 2, 4)]
 if len(sys.argv) > 1 and sys.argv[1] == 'xcd':
     variants = [('xcd-aware', (0, 0, 0, 0, 1, 0)), ('round-robin', (0, 0, 0, 0, 1, 64))]
 if len(sys.argv) > 1 and sys.argv[1] == 'depth':

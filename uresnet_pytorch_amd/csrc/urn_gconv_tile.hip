@@ -563,7 +563,11 @@ int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
     int rb = 0, cb = 0;
     for (int c = (nblk <= 5 ? nblk : 4); c >= 1 && !rb; --c) {
         if (nblk % c) continue;
-        for (int cand : {KS == 2 ? 2 : 4, KS == 2 ? 4 : 2, 1}) {   // 32-channel steps: two row blocks measured 10-15 % faster than four
+        // narrow inputs prefer few row blocks (sweep with the trimmed interleaved kernel, tools/bench_gconv.py narrow:
+        // 16 -> 16 one row block 14 us, two 16, four 17-18; 16 -> 32 22 vs 27; 32 -> 64 one row block 35 us vs 42 with two;
+        // 32 -> 32 and 32 -> 16 two row blocks)
+        const int first = KS == 1 ? 1 : (KS == 2 ? (c >= 4 ? 1 : 2) : 4);
+        for (int cand : {first, first == 4 ? 2 : (first == 2 ? 4 : 2), first == 1 ? 4 : 1}) {
             if (!lds_ok(cand, c)) continue;
             if (cand > 1 && (blocks16 / cand) * (nblk / c) < 100) continue;
             rb = cand; cb = c;
