@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw_small(const float *__restrict_
 }
 
 extern int g_opt_precision;
-int g_dw_split = 1;       // split-batch variants of k_gconv_dw2 for one- and two-block tiles: 0 never, 1 automatic, 2 always (urn_set_option "dw_split")
+int g_dw_split = 2;       // split-batch variants of k_gconv_dw2 for one- and two-block tiles: 0 never, 1 automatic, 2 always (urn_set_option "dw_split")
 int g_dw_kernel = 2;      // 2 = k_gconv_dw2 (default), 1 = k_gconv_dw (urn_set_option "dw_kernel")
 int g_dw_blocks = 1536;   // target number of workgroups of the weight-gradient kernel (urn_set_option "dw_blocks"); alone 2048 is the optimum, beside the dX chain 1536 (3.556 vs 3.595 ms per cfg3 step)
 
@@ -541,9 +541,9 @@ extern "C" int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, c
         else URN_DW2P(Sv, 0, KTv);
 #define URN_DW2(Sv) case Sv: URN_DW2K(Sv, 32) break;
         // The split variants keep all four matrix pipes of a CU busy: faster alone (16 x 16 at 50k rows: 29 -> 24 us;
-        // dense 128^3 model: 60.6 -> 49.6 ms per step), but in the sparse executor the weight gradients share the
-        // chip with the dX chain on the main stream and the step got 1.4 % slower -> automatic mode splits only
-        // launches large enough to own the chip.
+        // dense 128^3 model: 60.6 -> 49.6 ms per step).  Beside the dX chain of the sparse executor they were first
+        // 1.4 % slower per step (hence the automatic mode: only launches of >= 128k rows), with the final conv
+        // kernels 0.5 % faster (3.510 vs 3.527 ms) -> default: always.
         const bool split = g_dw_split == 2 || (g_dw_split == 1 && n_out >= 131072);
         if (nblk_max == 1 && split) { URN_DW2K(1, 128) }
         else if (nblk_max == 2 && split) { URN_DW2K(1, 64) }
