@@ -27,11 +27,11 @@ for name, fl in (('default', 0),):
 for s in variants.values():
     for _ in range(5): s()
 res = {k: [] for k in variants}
-kernels = {'dw split auto': 1, 'dw split always': 2, 'dw split never': 0}
+kernels = {'dw blocks 1024': 1024, 'dw blocks 1152': 1152, 'dw blocks 1280': 1280, 'dw blocks 1408': 1408, 'dw blocks 1536': 1536}
 res = {(k, kn): [] for k in variants for kn in kernels}
 for rnd in range(4):
     for kn, kv in kernels.items():
-        L.urn_set_option(b'dw_split', kv)
+        L.urn_set_option(b'dw_blocks', kv)
         for k, s in variants.items():
             for _ in range(2): s()
             torch.cuda.synchronize(); t0 = time.perf_counter()

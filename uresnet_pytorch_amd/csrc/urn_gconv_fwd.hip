@@ -279,7 +279,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "dw_kernel")) { g_dw_kernel = value == 1 ? 1 : 2; return URN_OK; }
     if (!strcmp(key, "dw_split")) { g_dw_split = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_group")) { g_dw_group = value > 0 ? (int)value : 1; return URN_OK; }
-    if (!strcmp(key, "dw_blocks")) { g_dw_blocks = value > 0 ? (int)value : 1536; return URN_OK; }
+    if (!strcmp(key, "dw_blocks")) { g_dw_blocks = value > 0 ? (int)value : 1152; return URN_OK; }
     if (!strcmp(key, "fin_in_kernel")) { g_opt_fin_in_kernel = value != 0; return URN_OK; }
     urn_set_error("urn_set_option: unknown key %s", key);
     return URN_EINVAL;
