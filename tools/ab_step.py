@@ -27,11 +27,11 @@ for name, fl in (('default', 0),):
 for s in variants.values():
     for _ in range(5): s()
 res = {k: [] for k in variants}
-kernels = {'dw blocks 1024': 1024, 'dw blocks 1152': 1152, 'dw blocks 1280': 1280, 'dw blocks 1408': 1408, 'dw blocks 1536': 1536}
+kernels = {'min wgs 100': 100, 'min wgs 150': 150, 'min wgs 200': 200, 'min wgs 250': 250, 'min wgs 300': 300}
 res = {(k, kn): [] for k in variants for kn in kernels}
 for rnd in range(4):
     for kn, kv in kernels.items():
-        L.urn_set_option(b'dw_blocks', kv)
+        L.urn_set_option(b'tile_min_wgs', kv)
         for k, s in variants.items():
             for _ in range(2): s()
             torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -517,6 +517,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 #endif
 URN_TILE_GLOBAL(int g_tile_depth, 0);   // kept for the option table; no effect
 URN_TILE_GLOBAL(int g_tile_il, 1);            // interleaved step (urn_set_option("tile_il", 0) = plain step)
+URN_TILE_GLOBAL(int g_tile_min_wgs, 100);      // a tile with several row blocks must leave this many workgroups (urn_set_option "tile_min_wgs")
 URN_TILE_GLOBAL(int g_tile_il_min_ks, 1);     // narrowest channel step that takes the interleaved variant (urn_set_option "tile_il_min_ks")
 
 template <int KS, int RB, int CB>
@@ -569,7 +570,7 @@ int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
         const int first = KS == 1 ? 1 : (KS == 2 ? (c >= 4 ? 1 : 2) : 4);
         for (int cand : {first, first == 4 ? 2 : (first == 2 ? 4 : 2), first == 1 ? 4 : 1}) {
             if (!lds_ok(cand, c)) continue;
-            if (cand > 1 && (blocks16 / cand) * (nblk / c) < 100) continue;
+            if (cand > 1 && (blocks16 / cand) * (nblk / c) < g_tile_min_wgs) continue;
             rb = cand; cb = c;
             break;
         }
