@@ -254,7 +254,7 @@ struct Pick { int mb, nb; };
 // before the column tile is widened
 extern long g_lds_min_wgs;
 int g_opt_precision = 0;   // default MFMA operand precision of the gather convolutions: 0 fp32, 1 bf16, 2 fp16
-extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_sum_slots;
+extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs;
 static int g_opt_dbg = 0;
 static int g_opt_fin_in_kernel = 0;
 static int g_opt_pipe = 0;
@@ -274,7 +274,6 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "tile_kc")) { g_tile_kc = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_depth")) { g_tile_depth = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_il")) { g_tile_il = (int)value; return URN_OK; }
-    if (!strcmp(key, "sum_slots")) { g_sum_slots = value >= 1 && value <= 64 ? (int)value : 8; return URN_OK; }
     if (!strcmp(key, "tile_min_wgs")) { g_tile_min_wgs = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_il_min_ks")) { g_tile_il_min_ks = (int)value; return URN_OK; }
     if (!strcmp(key, "gconv_precision")) { g_opt_precision = value >= 0 && value <= 2 ? (int)value : 0; return URN_OK; }
