@@ -17,6 +17,10 @@ from . import scn
 from . import sparse_ops as so
 
 
+MAX_SIDE_STREAMS = 2
+_SIDE_HANDLES = 0      # executor handles of this process that own a side stream
+
+
 class _Token:
     """Lives as long as the autograd node of one forward; a slot is busy while its token is alive."""
     pass
@@ -47,13 +51,25 @@ class TrunkExecutor:
         self.flat_grad = None
         self._ws_coef = {}
         self._prep = None
+        self._side_handles = 0
 
     # -- handle ------------------------------------------------------------------------
     def _new_handle(self):
+        """A new executor handle.  Every handle with a side stream adds a HIP stream to the process, and HIP multiplexes
+        streams onto a few hardware queues: from the fourth such handle on a step was measured 2.7x slower (a queue
+        shared with the caller's stream).  So at most MAX_SIDE_STREAMS handles per process get a side stream; further
+        ones (many models in one process, gradient accumulation over many forwards) run single-stream."""
+        global _SIDE_HANDLES
         L = _l.load()
         h = ctypes.c_void_p()
-        _l.check(L.urn_net_create(*self.cfg, float(self.eps), float(self.momentum), int(self.flags), ctypes.byref(h)),
-                 'net_create')
+        flags = int(self.flags)
+        with_side = not (flags & 2) and _SIDE_HANDLES < MAX_SIDE_STREAMS
+        if not with_side:
+            flags |= 2                                  # URN_NET_SINGLE_STREAM
+        _l.check(L.urn_net_create(*self.cfg, float(self.eps), float(self.momentum), flags, ctypes.byref(h)), 'net_create')
+        if with_side:
+            _SIDE_HANDLES += 1
+            self._side_handles += 1
         return h
 
     def acquire(self):
@@ -88,6 +104,8 @@ class TrunkExecutor:
         assert self.n_running == sum(2 * b.nPlanes for b in bn)
 
     def __del__(self):
+        global _SIDE_HANDLES
+        _SIDE_HANDLES -= getattr(self, '_side_handles', 0)
         try:
             handles = [s.handle for s in self.slots] or ([self.handle] if self.handle is not None else [])
             for h in handles:
