@@ -295,7 +295,9 @@ int urn_prof_enable(int on);
  *   "tile_il" 1/0 interleaved offset step, "tile_il_min_ks" narrowest channel step that takes it;
  *   "tile_rb" / "tile_cb" / "tile_kc" force the workgroup tile / channels per step (0 = automatic);
  *   "dw_kernel" 2/1, "dw_blocks" workgroup target, "dw_split" 0 never | 1 automatic | 2 always, "dw_group"
- *   weight gradients per fork to the side stream; "fin_in_kernel" finalize BatchNorm statistics by the last
+ *   weight gradients per fork to the side stream; "net_side_probe" candidate side streams an executor's first
+ *   backward times against the caller's stream (default 4; 0 keeps the first), "net_side_verbose" 1 prints the
+ *   probe times to stderr; "fin_in_kernel" finalize BatchNorm statistics by the last
  *   workgroup (slab mode); "gconv_dbg" timing-only ablation / probe mask (results are garbage with most bits);
  *   "gconv_pipe", "gconv_min_waves", "gconv_lds_min_wgs" knobs of the older kernels. */
 int urn_set_option(const char *key, int64_t value);

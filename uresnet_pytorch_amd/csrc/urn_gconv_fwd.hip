@@ -254,7 +254,7 @@ struct Pick { int mb, nb; };
 // before the column tile is widened
 extern long g_lds_min_wgs;
 int g_opt_precision = 0;   // default MFMA operand precision of the gather convolutions: 0 fp32, 1 bf16, 2 fp16
-extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs;
+extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
 static int g_opt_fin_in_kernel = 0;
 static int g_opt_pipe = 0;
@@ -279,6 +279,8 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "gconv_precision")) { g_opt_precision = value >= 0 && value <= 2 ? (int)value : 0; return URN_OK; }
     if (!strcmp(key, "dw_kernel")) { g_dw_kernel = value == 1 ? 1 : 2; return URN_OK; }
     if (!strcmp(key, "dw_split")) { g_dw_split = (int)value; return URN_OK; }
+    if (!strcmp(key, "net_side_probe")) { g_net_side_probe = (int)value; return URN_OK; }
+    if (!strcmp(key, "net_side_verbose")) { g_net_side_verbose = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_group")) { g_dw_group = value > 0 ? (int)value : 1; return URN_OK; }
     if (!strcmp(key, "dw_blocks")) { g_dw_blocks = value > 0 ? (int)value : 1152; return URN_OK; }
     if (!strcmp(key, "fin_in_kernel")) { g_opt_fin_in_kernel = value != 0; return URN_OK; }

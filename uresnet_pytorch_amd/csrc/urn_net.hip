@@ -14,10 +14,46 @@
 #include <string.h>
 #include <memory>
 #include <vector>
+#include <chrono>
 
 int g_dw_group = 1;   // weight gradients per fork to the side stream (urn_set_option "dw_group"); measured: 1: 3.61 ms, 2: 3.66, 4: 3.64, 8: 3.74, 16: 3.85
 
+int g_net_side_probe = 4;   // candidate side streams tried by an executor's first backward (urn_set_option "net_side_probe"; 0/1 = keep the first)
+int g_net_side_verbose = 0;
+
 namespace {
+
+// Side-stream probe.  HIP multiplexes streams onto a few hardware queues, and some (main stream, side stream) pairs
+// run the fork -> concurrent kernels pattern of the backward pass 2.5x slower than others (measured: the 4th and 5th
+// executor of a process with GPU_MAX_HW_QUEUES=4, the 4th with 8; which one is hit depends on how many streams the
+// process -- torch, RCCL -- has created before).  The mapping cannot be queried, so the first backward of an
+// executor times the pattern itself on a few candidate streams and keeps the fastest.
+__global__ void k_probe_spin(long ticks)
+{
+    const long t0 = (long)wall_clock64();            // 100 MHz; bounded: every wave leaves after `ticks`
+    while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+double urn_now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+double probe_pair(hipStream_t main, hipStream_t side, const std::vector<hipEvent_t> &ev, int rounds)
+{
+    if (hipStreamSynchronize(main) != hipSuccess) return 1e30;
+    const double t0 = urn_now_ms();
+    for (int r = 0; r < rounds; ++r) {
+        hipEvent_t e = ev[r % ev.size()];
+        if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return 1e30;
+        hipLaunchKernelGGL(k_probe_spin, dim3(64), dim3(64), 0, side, 1500L);          // ~15 us, like a weight gradient
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_probe_spin, dim3(64), dim3(64), 0, main, 300L);   // the dX chain
+    }
+    hipEvent_t e = ev[rounds % ev.size()];
+    if (hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) return 1e30;
+    if (hipStreamSynchronize(main) != hipSuccess) return 1e30;
+    return urn_now_ms() - t0;
+}
 
 struct Arena {
     char *base = nullptr;
@@ -91,6 +127,32 @@ struct urn_net {
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
     bool side_used = false;
+    bool side_probed = false;
+    // keep the fastest of g_net_side_probe candidate side streams for this executor's main stream (see probe_pair)
+    void pick_side()
+    {
+        side_probed = true;
+        if (g_net_side_probe < 2 || events.size() < 64) return;
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        std::vector<hipStream_t> cand{side};
+        for (int i = 1; i < g_net_side_probe; ++i) {
+            hipStream_t c = nullptr;
+            if (hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prio_lo) != hipSuccess) { (void)hipGetLastError(); break; }
+            cand.push_back(c);
+        }
+        int best = 0; double best_ms = 1e30;
+        for (size_t i = 0; i < cand.size(); ++i) {
+            (void)probe_pair(st, cand[i], events, 4);
+            const double ms = std::min(probe_pair(st, cand[i], events, 16), probe_pair(st, cand[i], events, 16));
+            if (g_net_side_verbose) fprintf(stderr, "urn_net: side stream candidate %zu: %.3f ms\n", i, ms);
+            if (ms < best_ms * 0.8) { best_ms = ms; best = (int)i; }   // later candidates must be clearly better
+        }
+        (void)hipGetLastError();
+        for (size_t i = 0; i < cand.size(); ++i)
+            if ((int)i != best) { (void)hipStreamSynchronize(cand[i]); (void)hipStreamDestroy(cand[i]); }
+        side = cand[best];
+    }
     float *wt_all = nullptr;             // transposed copy of every conv weight, same offsets as params
     std::vector<ConvP *> convs;          // every conv, for the batched transpose
     int rc = URN_OK;
@@ -827,6 +889,7 @@ extern "C" int urn_net_backward(urn_net *net, const float *d_rows, float *grads,
 {
     URN_CHECK_ARG(net && d_rows && grads && net->trunk_out, "null pointer or no forward recorded");
     net->grads = grads; net->st = (hipStream_t)stream;
+    if (net->side && !net->side_probed) net->pick_side();
     run_backward(net, d_rows);
     if (net->arena.overflow) { urn_set_error("urn_net_backward: workspace too small (%zu needed)", net->arena.peak); return URN_EINVAL; }
     return net->rc;

@@ -17,7 +17,7 @@ from . import scn
 from . import sparse_ops as so
 
 
-MAX_SIDE_STREAMS = 2
+MAX_SIDE_STREAMS = 8
 _SIDE_HANDLES = 0      # executor handles of this process that own a side stream
 
 
@@ -56,9 +56,11 @@ class TrunkExecutor:
     # -- handle ------------------------------------------------------------------------
     def _new_handle(self):
         """A new executor handle.  Every handle with a side stream adds a HIP stream to the process, and HIP multiplexes
-        streams onto a few hardware queues: from the fourth such handle on a step was measured 2.7x slower (a queue
-        shared with the caller's stream).  So at most MAX_SIDE_STREAMS handles per process get a side stream; further
-        ones (many models in one process, gradient accumulation over many forwards) run single-stream."""
+        streams onto a few hardware queues: some (caller stream, side stream) pairs run a step 2.7x slower (measured:
+        the 4th and 5th handle of a process).  The executor's first backward therefore probes a few candidate side
+        streams and keeps the fastest (urn_net.hip pick_side); MAX_SIDE_STREAMS only bounds how many streams a process
+        with many handles (many models, gradient accumulation over many forwards) creates -- further handles run
+        single-stream."""
         global _SIDE_HANDLES
         L = _l.load()
         h = ctypes.c_void_p()
@@ -105,7 +107,10 @@ class TrunkExecutor:
 
     def __del__(self):
         global _SIDE_HANDLES
-        _SIDE_HANDLES -= getattr(self, '_side_handles', 0)
+        try:
+            _SIDE_HANDLES -= getattr(self, '_side_handles', 0)
+        except TypeError:        # interpreter shutdown: module globals are already gone
+            pass
         try:
             handles = [s.handle for s in self.slots] or ([self.handle] if self.handle is not None else [])
             for h in handles:
