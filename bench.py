@@ -174,7 +174,7 @@ def main():
             'algorithmic_gflop_per_step': round(flops_step / 1e9, 3),
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU leg is reported at N=1 only
             from oracle import sparse_oracle as orc
             P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if 'running' not in k}
             ref = orc.SparseUResNetOracle(P, FILTERS, STRIDES, NCLASS, SPATIAL)
