@@ -8,6 +8,7 @@ own event(s) (rank r uses generator seeds r*E .. r*E+E-1), so whole-job voxels g
 Inputs are synthetic (SURVEY App. D generator) and resident in HBM before timing starts.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline_hbm -- the integer phase (hash / unique / rulebook kernels) against the HBM roofline, same method;
   roofline     -- dominant kernel (gather-conv MFMA kernel, forward + input-gradient launches):
                   algorithmic FLOPs (2*R*Cin*Cout per launch, R = rules of that launch) divided by
                   the kernel's launch durations measured with HIP events on the launch stream;
@@ -30,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 SPATIAL, VOXELS, FILTERS, STRIDES, NCLASS = 512, 50000, 16, 5, 5
 
 
@@ -153,11 +155,24 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         from uresnet_pytorch_amd import sparse_ops as so
-        geo = so.SparseGeometry(data[:, :4].to(torch.int32), SPATIAL, STRIDES)
-        flops_step, launches_step = conv_launch_flops(model, geo)
         ms = ctypes.c_double(); n = ctypes.c_int64()
         urn_lib.check(L.urn_prof_read(0, ctypes.byref(ms), ctypes.byref(n)))
+        ims = ctypes.c_double(); inn = ctypes.c_int64()
+        urn_lib.check(L.urn_prof_read(2, ctypes.byref(ims), ctypes.byref(inn)))
         urn_lib.check(L.urn_prof_enable(0))
+        geo = so.SparseGeometry(data[:, :4].to(torch.int32), SPATIAL, STRIDES)
+        flops_step, launches_step = conv_launch_flops(model, geo)
+        # integer phase (site hash + unique per level, strided tables, 27-probe rulebook of every level): HBM-bound.
+        # Algorithmic bytes per SURVEY 8(d): 4*(d+1)*N coordinates + 16*N hash slot traffic + 4*27*N table, per level.
+        int_bytes = sum((4 * 4 + 16 + 4 * 27) * int(nl) for nl in geo.n)
+        int_gbs = int_bytes * PSTEPS / (ims.value * 1e-3) / 1e9 if ims.value > 0 else 0.0
+        roofline_hbm = {
+            'bound': 'hbm', 'kernel': 'integer phase: k_insert/k_flag_count/k_assign/k_row2site|k_parent_off per level + '
+                                      'k_rulebook_subm_multi (%d library calls per step)' % (inn.value // PSTEPS),
+            'achieved': round(int_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(int_gbs / PEAK_HBM_GBS, 5),
+            'traffic': None, 'algorithmic_mb_per_step': round(int_bytes / 1e6, 2),
+            'us_per_step': round(1e3 * ims.value / PSTEPS, 1),
+        }
         achieved = (flops_step * PSTEPS) / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         # HBM traffic of the same kernel: measured in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) and
         # committed under profiles/ (bench.py cannot read PMC counters itself); null when no measurement is committed
@@ -195,7 +210,7 @@ def main():
                                    'fp32, step = fwd+loss+bwd+grad all-reduce(SUM)+Adam' % (E, VOXELS),
                        'events_per_gpu': E, 'voxels_per_event': VOXELS, 'parallelism': 'dp%d (events sharded, '
                        'one RCCL all-reduce per step)' % world},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_hbm': roofline_hbm, 'cpu_baseline': cpu,
         }
     if world > 1:
         dist.barrier()

@@ -284,7 +284,8 @@ int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stre
 
 /* ----------------------------------------------------------------------- measurement
  * Optional per-kernel timing (HIP events on the launch stream), off by default.
- * kind 0 = gather-conv forward/input-gradient kernel, 1 = weight-gradient kernel.
+ * kind 0 = gather-conv forward/input-gradient kernel, 1 = weight-gradient kernel, 2 = integer phase (one record per
+ * urn_sites_build / urn_level_down_tables / urn_rulebook_subm_multi call).
  * urn_prof_enable resets the records; urn_prof_read waits for the recorded events. */
 int urn_prof_enable(int on);
 /* Library-wide options.  Behaviour:

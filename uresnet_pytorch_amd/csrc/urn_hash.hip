@@ -6,6 +6,7 @@
 // Replaces the host-side hash-map work behind scn.InputLayer / scn.SubmanifoldConvolution /
 // scn.Convolution at reference uresnet/models/uresnet_sparse.py:20-22.
 #include "urn_common.h"
+#include "urn_prof.h"
 #include <stdarg.h>
 
 static thread_local char g_err[512] = "";
@@ -238,6 +239,8 @@ extern "C" int urn_sites_build(const int32_t *coords, int64_t n, int spatial, vo
     URN_CHECK_ARG(n < 0x7F000000ll, "too many rows");
     hipStream_t st = (hipStream_t)stream;
     int *rowslot;
+    const bool prof = urn_prof_on();
+    if (prof) urn_prof_begin(URN_PROF_INTEGER, st);
     int rc = run_unique(coords, nullptr, n, 0, hash, hcap, scratch, scratch_bytes, site_coords, n_active,
                         &rowslot, st);
     if (rc) return rc;
@@ -246,6 +249,7 @@ extern "C" int urn_sites_build(const int32_t *coords, int64_t n, int spatial, vo
         hipLaunchKernelGGL(k_row2site, dim3((int)n_blocks(n)), dim3(UB), 0, st, (const int *)nullptr, (long)n,
                            h, rowslot, row2site);
     }
+    if (prof) urn_prof_end(st);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
@@ -269,6 +273,8 @@ extern "C" int urn_level_down_tables(const int32_t *fine_coords, const int32_t *
     URN_CHECK_ARG((chd == nullptr) == (up == nullptr), "chd and up go together");
     hipStream_t st = (hipStream_t)stream;
     int *rowslot;
+    const bool prof = urn_prof_on();
+    if (prof) urn_prof_begin(URN_PROF_INTEGER, st);
     int rc = run_unique(fine_coords, n_fine, n_cap, 1, hash, hcap, scratch, scratch_bytes, coarse_coords,
                         n_coarse, &rowslot, st);
     if (rc) return rc;
@@ -277,6 +283,7 @@ extern "C" int urn_level_down_tables(const int32_t *fine_coords, const int32_t *
         hipLaunchKernelGGL(k_parent_off, dim3((int)n_blocks(n_cap)), dim3(UB), 0, st, fine_coords, n_fine,
                            (long)n_cap, h, rowslot, parent, off, chd, (long)ld_c, up, (long)ld_f);
     }
+    if (prof) urn_prof_end(st);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
@@ -383,8 +390,11 @@ extern "C" int urn_rulebook_subm_multi(int num_levels, const int32_t *const *sit
         lv.coords[l] = site_coords[l]; lv.n_dev[l] = n_dev[l]; lv.nbr[l] = nbr[l];
         lv.h[l] = hash_view((void *)hash[l], hcap); lv.spatial[l] = spatial[l];
     }
+    const bool prof = urn_prof_on();
+    if (prof) urn_prof_begin(URN_PROF_INTEGER, (hipStream_t)stream);
     hipLaunchKernelGGL(k_rulebook_subm_multi, dim3(urn_cdiv(n_cap, 256), 27, num_levels), dim3(256), 0, (hipStream_t)stream,
                        lv, (long)n_cap, (long)ld);
+    if (prof) urn_prof_end((hipStream_t)stream);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
