@@ -162,12 +162,12 @@ def main():
         urn_lib.check(L.urn_prof_enable(0))
         geo = so.SparseGeometry(data[:, :4].to(torch.int32), SPATIAL, STRIDES)
         flops_step, launches_step = conv_launch_flops(model, geo)
-        # integer phase (site hash + unique per level, strided tables, 27-probe rulebook of every level): HBM-bound.
+        # integer phase (site hash + unique of every level, strided tables, 27-probe rulebook of every level): HBM-bound.
         # Algorithmic bytes per SURVEY 8(d): 4*(d+1)*N coordinates + 16*N hash slot traffic + 4*27*N table, per level.
         int_bytes = sum((4 * 4 + 16 + 4 * 27) * int(nl) for nl in geo.n)
         int_gbs = int_bytes * PSTEPS / (ims.value * 1e-3) / 1e9 if ims.value > 0 else 0.0
         roofline_hbm = {
-            'bound': 'hbm', 'kernel': 'integer phase: k_insert/k_flag_count/k_assign/k_row2site|k_parent_off per level + '
+            'bound': 'hbm', 'kernel': 'integer phase: k_insert_lv/k_flag_count_lv/k_assign_lv/k_links_lv (all levels per launch) + '
                                       'k_rulebook_subm_multi (%d library calls per step)' % (inn.value // PSTEPS),
             'achieved': round(int_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(int_gbs / PEAK_HBM_GBS, 5),
             'traffic': None, 'algorithmic_mb_per_step': round(int_bytes / 1e6, 2),

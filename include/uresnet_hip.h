@@ -82,6 +82,18 @@ int urn_level_down_tables(const int32_t *fine_coords, const int32_t *n_fine, int
                           int64_t hcap, void *scratch, int64_t scratch_bytes, int32_t *coarse_coords,
                           int32_t *parent, int32_t *off, int32_t *n_coarse, int32_t *chd, int64_t ld_c,
                           int32_t *up, int64_t ld_f, void *stream);
+/* Sites of ALL levels of one geometry from the input rows in four launches: the results of urn_sites_build followed by
+ * num_levels-1 urn_level_down_tables calls (same site numbering: level l's sites are the distinct (coords >> l, batch) of
+ * the rows, numbered by first occurrence -- see urn_hash.hip for why that equals the level-by-level numbering).
+ * Arrays of num_levels host pointers: hash (each hcap slots, cleared), site_coords [n][4]; of num_levels-1: parent, off
+ * [n], chd, up ([8][ld], pre-filled with -1; the arrays may be NULL).  n_sites: device int32[num_levels].
+ * scratch: urn_levels_scratch_bytes(n, num_levels).  Replaces scn.InputLayer + the metadata of scn.Convolution(2,2)
+ * (reference uresnet/models/uresnet_sparse.py:20-22). */
+int64_t urn_levels_scratch_bytes(int64_t n, int num_levels);
+int urn_sites_build_levels(const int32_t *coords, int64_t n, int spatial, int num_levels, void *const *hash,
+                           int64_t hcap, void *scratch, int64_t scratch_bytes, int32_t *row2site,
+                           int32_t *const *site_coords, int32_t *n_sites, int32_t *const *parent,
+                           int32_t *const *off, int32_t *const *chd, int32_t *const *up, int64_t ld, void *stream);
 /* urn_rulebook_subm for up to 8 levels of one geometry in a single launch: arrays of num_levels host pointers /
  * values (site coordinates, device counts, spatial sizes, hashes of capacity hcap, tables [27][ld]) */
 int urn_rulebook_subm_multi(int num_levels, const int32_t *const *site_coords, const int32_t *const *n_dev,
@@ -285,7 +297,7 @@ int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stre
 /* ----------------------------------------------------------------------- measurement
  * Optional per-kernel timing (HIP events on the launch stream), off by default.
  * kind 0 = gather-conv forward/input-gradient kernel, 1 = weight-gradient kernel, 2 = integer phase (one record per
- * urn_sites_build / urn_level_down_tables / urn_rulebook_subm_multi call).
+ * urn_sites_build / urn_sites_build_levels / urn_level_down_tables / urn_rulebook_subm_multi call).
  * urn_prof_enable resets the records; urn_prof_read waits for the recorded events. */
 int urn_prof_enable(int on);
 /* Library-wide options.  Behaviour:

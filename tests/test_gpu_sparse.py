@@ -42,23 +42,26 @@ def dev():
 
 
 def check_geometry(c, f, S, L, dev):
+    """Both routes of the integer phase against the oracle: all levels at once from the input rows
+    (urn_sites_build_levels, the default) and level by level (urn_sites_build + urn_level_down_tables)."""
     from uresnet_pytorch_amd import sparse_ops as so
-    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, L)
     ref = orc.Geometry(c, f, S, L)
-    assert geo.n == ref.n
-    assert np.array_equal(geo.row2site[:len(c)].cpu().numpy(), ref.row2site)
-    for l in range(L):
-        assert np.array_equal(geo.export_coords(l), ref.coords[l]), 'site coords level %d' % l
-        assert np.array_equal(geo.export_nbr(l), ref.nbr[l]), 'subm table level %d' % l
-        assert geo.rules[l] == ref.R[l]
-        # canonical (offset, in, out) triples, sorted
-        assert np.array_equal(orc.canonical_triples(geo.export_nbr(l)), orc.canonical_triples(ref.nbr[l]))
-        if l + 1 < L:
-            n, nc = geo.n[l], geo.n[l + 1]
-            assert np.array_equal(geo.parent[l][:n].cpu().numpy(), ref.parent[l])
-            assert np.array_equal(geo.off[l][:n].cpu().numpy(), ref.off[l])
-            assert np.array_equal(geo.chd[l][:, :nc].cpu().numpy(), ref.chd[l])
-            assert np.array_equal(geo.up[l][:, :n].cpu().numpy(), ref.up[l])
+    for per_level in (True, False):
+        geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, L, per_level=per_level)
+        assert geo.n == ref.n
+        assert np.array_equal(geo.row2site[:len(c)].cpu().numpy(), ref.row2site)
+        for l in range(L):
+            assert np.array_equal(geo.export_coords(l), ref.coords[l]), 'site coords level %d' % l
+            assert np.array_equal(geo.export_nbr(l), ref.nbr[l]), 'subm table level %d' % l
+            assert geo.rules[l] == ref.R[l]
+            # canonical (offset, in, out) triples, sorted
+            assert np.array_equal(orc.canonical_triples(geo.export_nbr(l)), orc.canonical_triples(ref.nbr[l]))
+            if l + 1 < L:
+                n, nc = geo.n[l], geo.n[l + 1]
+                assert np.array_equal(geo.parent[l][:n].cpu().numpy(), ref.parent[l])
+                assert np.array_equal(geo.off[l][:n].cpu().numpy(), ref.off[l])
+                assert np.array_equal(geo.chd[l][:, :nc].cpu().numpy(), ref.chd[l])
+                assert np.array_equal(geo.up[l][:, :n].cpu().numpy(), ref.up[l])
     sf = so.input_features(geo, torch.from_numpy(f).to(dev)).cpu().numpy()
     assert np.array_equal(sf, ref.feats)       # fp64 accumulation, one rounding: bit-exact
     return geo, ref

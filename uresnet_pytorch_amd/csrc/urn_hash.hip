@@ -288,6 +288,151 @@ extern "C" int urn_level_down_tables(const int32_t *fine_coords, const int32_t *
     return URN_OK;
 }
 
+// ---- all levels of a geometry from the input rows ------------------------------------------------------------
+// Level l's sites are the distinct (x >> l, y >> l, z >> l, batch) of the INPUT ROWS numbered by first occurrence among the
+// rows.  That is the numbering the level-by-level pipeline gives (first occurrence among the level l-1 sites in index
+// order): level-(l-1) sites are ordered by their smallest row, so the first level-(l-1) site below a level-l key is the one
+// holding the key's smallest row, and keys ordered by "first site" are ordered by "smallest row".  The levels therefore do
+// not depend on each other and every stage runs once for all of them (grid.y = level): 4 launches instead of 4 per level.
+#define URN_GEO_MAX_LEVELS 8
+struct GeoLevels {
+    HashView h[URN_GEO_MAX_LEVELS];
+    int *site_coords[URN_GEO_MAX_LEVELS];
+    int *parent[URN_GEO_MAX_LEVELS], *off[URN_GEO_MAX_LEVELS], *chd[URN_GEO_MAX_LEVELS], *up[URN_GEO_MAX_LEVELS];
+};
+
+__global__ void k_insert_lv(const int *__restrict__ coords, long n, GeoLevels g, int *__restrict__ rowslot)
+{
+    const int l = blockIdx.y;
+    const long i = (long)blockIdx.x * UB + threadIdx.x;
+    if (i >= n) return;
+    const HashView h = g.h[l];
+    const int4 c = ((const int4 *)coords)[i];
+    const unsigned long long key = urn_key(c.x >> l, c.y >> l, c.z >> l, c.w);
+    unsigned long long s = urn_mix(key) & h.mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&h.keys[s], URN_EMPTY_KEY, key);
+        if (prev == URN_EMPTY_KEY || prev == key) break;
+        s = (s + 1) & h.mask;
+    }
+    atomicMin(&h.first[s], (int)i);
+    rowslot[(long)l * n + i] = (int)s;
+}
+
+__global__ void k_flag_count_lv(long n, GeoLevels g, const int *__restrict__ rowslot, int *__restrict__ blocksum)
+{
+    const int l = blockIdx.y;
+    const long i = (long)blockIdx.x * UB + threadIdx.x;
+    const bool f = (i < n) && (g.h[l].first[rowslot[(long)l * n + i]] == (int)i);
+    int tot;
+    block_prefix(f, &tot);
+    if (threadIdx.x == 0) blocksum[(long)l * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ void k_assign_lv(const int *__restrict__ coords, long n, GeoLevels g, const int *__restrict__ rowslot,
+                            const int *__restrict__ blocksum, int *__restrict__ site_row, int *__restrict__ n_sites)
+{
+    __shared__ int s_part[UB / 64];
+    const int l = blockIdx.y;
+    const HashView h = g.h[l];
+    const long i = (long)blockIdx.x * UB + threadIdx.x;
+    const int slot = (i < n) ? rowslot[(long)l * n + i] : 0;
+    const bool f = (i < n) && (h.first[slot] == (int)i);
+    const int *bs = blocksum + (long)l * gridDim.x;
+    int mine = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += UB) mine += bs[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < UB / 64; ++k) base += s_part[k];
+    int tot;
+    const int pre = block_prefix(f, &tot);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) n_sites[l] = base + tot;
+    if (f) {
+        const int s = base + pre;
+        int4 c = ((const int4 *)coords)[i];
+        c.x >>= l; c.y >>= l; c.z >>= l;
+        ((int4 *)g.site_coords[l])[s] = c;
+        h.site[slot] = s;
+        site_row[(long)l * n + s] = (int)i;
+    }
+}
+
+// input row -> level-0 site; level-l site -> parent at level l+1, 2^3 offset, and the gather tables of the strided pair
+__global__ void k_links_lv(long n, int num_levels, GeoLevels g, const int *__restrict__ rowslot,
+                           const int *__restrict__ site_row, const int *__restrict__ n_sites,
+                           int *__restrict__ row2site, long ld)
+{
+    const int l = blockIdx.y;
+    const long i = (long)blockIdx.x * UB + threadIdx.x;
+    if (l == 0 && i < n) row2site[i] = g.h[0].site[rowslot[i]];
+    if (l + 1 >= num_levels || i >= (long)n_sites[l]) return;
+    const int r = site_row[(long)l * n + i];
+    const int p = g.h[l + 1].site[rowslot[(long)(l + 1) * n + r]];
+    const int4 c = ((const int4 *)g.site_coords[l])[i];
+    const int o = ((c.x & 1) * 2 + (c.y & 1)) * 2 + (c.z & 1);
+    g.parent[l][i] = p;
+    g.off[l][i] = o;
+    if (g.chd[l]) {
+        g.chd[l][(long)o * ld + p] = (int)i;
+        g.up[l][(long)o * ld + i] = p;
+    }
+}
+
+extern "C" int64_t urn_levels_scratch_bytes(int64_t n, int num_levels)
+{
+    // rowslot[L][n] | site_row[L][n] | blocksum[L][nblk]
+    return ((int64_t)num_levels * (8 * n + 4 * n_blocks(n)) + 255) / 256 * 256 + 256;
+}
+
+extern "C" int urn_sites_build_levels(const int32_t *coords, int64_t n, int spatial, int num_levels, void *const *hash,
+                                      int64_t hcap, void *scratch, int64_t scratch_bytes, int32_t *row2site,
+                                      int32_t *const *site_coords, int32_t *n_sites, int32_t *const *parent,
+                                      int32_t *const *off, int32_t *const *chd, int32_t *const *up, int64_t ld,
+                                      void *stream)
+{
+    URN_CHECK_ARG(n >= 0 && num_levels >= 1 && num_levels <= URN_GEO_MAX_LEVELS && hash && scratch && n_sites && site_coords,
+                  "bad argument");
+    URN_CHECK_ARG(n == 0 || (coords && row2site), "null pointer");
+    URN_CHECK_ARG(num_levels == 1 || (parent && off), "null pointer");
+    URN_CHECK_ARG(spatial > 0 && spatial <= 32768, "spatial size must be in 1..32768");
+    URN_CHECK_ARG(n < 0x7F000000ll / num_levels, "too many rows");
+    URN_CHECK_ARG(scratch_bytes >= urn_levels_scratch_bytes(n, num_levels), "scratch too small");
+    URN_CHECK_ARG((hcap & (hcap - 1)) == 0 && hcap >= 2 * n, "hash capacity must be a power of two >= 2n");
+    URN_CHECK_ARG(ld >= n, "ld < n");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (hipMemsetAsync(n_sites, 0, 4 * (size_t)num_levels, st) != hipSuccess) { urn_set_error("urn_sites_build_levels: memset failed"); return URN_EHIP; }
+        return URN_OK;
+    }
+    GeoLevels g;
+    for (int l = 0; l < num_levels; ++l) {
+        URN_CHECK_ARG(hash[l] && site_coords[l], "null pointer");
+        g.h[l] = hash_view(hash[l], hcap);
+        g.site_coords[l] = site_coords[l];
+        const bool link = l + 1 < num_levels;
+        URN_CHECK_ARG(!link || (parent[l] && off[l]), "null pointer");
+        URN_CHECK_ARG(!link || !chd || !up || ((chd[l] == nullptr) == (up[l] == nullptr)), "chd and up go together");
+        g.parent[l] = link ? parent[l] : nullptr; g.off[l] = link ? off[l] : nullptr;
+        g.chd[l] = link && chd && up ? chd[l] : nullptr; g.up[l] = link && chd && up ? up[l] : nullptr;
+    }
+    int *rowslot = (int *)scratch, *site_row = rowslot + (long)num_levels * n, *blocksum = site_row + (long)num_levels * n;
+    const int nblk = (int)n_blocks(n);
+    const dim3 grid(nblk, num_levels);
+    const bool prof = urn_prof_on();
+    if (prof) urn_prof_begin(URN_PROF_INTEGER, st);
+    hipLaunchKernelGGL(k_insert_lv, grid, dim3(UB), 0, st, coords, (long)n, g, rowslot);
+    hipLaunchKernelGGL(k_flag_count_lv, grid, dim3(UB), 0, st, (long)n, g, rowslot, blocksum);
+    hipLaunchKernelGGL(k_assign_lv, grid, dim3(UB), 0, st, coords, (long)n, g, rowslot, blocksum, site_row, n_sites);
+    hipLaunchKernelGGL(k_links_lv, grid, dim3(UB), 0, st, (long)n, num_levels, g, rowslot, site_row, n_sites, row2site, (long)ld);
+    if (prof) urn_prof_end(st);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
 __global__ void k_down_tables(const int *__restrict__ parent, const int *__restrict__ off, const int *n_dev,
                               long n_cap, int *__restrict__ chd, long ld_c, int *__restrict__ up, long ld_f)
 {

@@ -56,6 +56,9 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p]),
     'urn_level_down_tables': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
+    'urn_levels_scratch_bytes': (c_i64, [c_i64, c_int]),
+    'urn_sites_build_levels': (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'urn_rulebook_subm_multi': (c_int, [c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
                                         c_void_p]),
     'urn_down_tables': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),

@@ -18,10 +18,12 @@ class SparseGeometry:
     (uresnet/models/uresnet_sparse.py:20-22).
     """
 
-    def __init__(self, coords, spatial_size, num_levels=1, defer_sync=False):
+    def __init__(self, coords, spatial_size, num_levels=1, defer_sync=False, per_level=False):
         """defer_sync=True: everything is enqueued but the level counts are not read back yet -- the caller does the
         rest of its host-side preparation (measured: host time after this synchronisation is exposed one to one in
-        the step, host time before it is hidden behind the previous step's kernels) and then calls sync()."""
+        the step, host time before it is hidden behind the previous step's kernels) and then calls sync().
+        per_level=True: build the pyramid level by level (urn_sites_build + urn_level_down_tables per level) instead of
+        all levels at once from the input rows (urn_sites_build_levels); same results, kept for the per-call C ABI."""
         _l.require_gpu(coords)
         L = _l.load()
         assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
@@ -42,44 +44,57 @@ class SparseGeometry:
         self.hash = torch.empty(self.num_levels * hbytes, dtype=torch.uint8, device=dev)
         _l.check(L.urn_hash_clear(self.hash.data_ptr(), self.hash.numel(), st), 'hash_clear')
         self._hptr = [self.hash.data_ptr() + l * hbytes for l in range(self.num_levels)]
-        sbytes = L.urn_unique_scratch_bytes(cap)
-        scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
-        # counts: [n_l for each level] + [rules_l for each level]
-        self.counts = torch.zeros(2 * self.num_levels, dtype=torch.int32, device=dev)
-        cptr = self.counts.data_ptr()
-        self.row2site = torch.empty(cap, dtype=torch.int32, device=dev)
-        self.coords = [torch.empty((cap, 4), dtype=torch.int32, device=dev)]
-        _l.check(L.urn_sites_build(coords.data_ptr(), N, self.spatial, self._hptr[0], hcap, scratch.data_ptr(),
-                                   sbytes, self.row2site.data_ptr(), self.coords[0].data_ptr(), cptr, st),
-                 'sites_build')
-        self.ld = cap                      # leading dimension of every gather table
-        self.nbr, self.parent, self.off, self.chd, self.up = [], [], [], [], []
-        sp = self.spatial
-        spatials = []
-        # strided tables are filled with -1 by one launch
-        if self.num_levels > 1:
-            self._strided = torch.empty((self.num_levels - 1, 2, 8, cap), dtype=torch.int32, device=dev)
-            _l.check(L.urn_fill_i32(self._strided.data_ptr(), self._strided.numel(), -1, st), 'fill')
-        self._nbr_all = torch.empty((self.num_levels, 27, cap), dtype=torch.int32, device=dev)
-        for l in range(self.num_levels):
-            n_dev = cptr + 4 * l
-            if l + 1 < self.num_levels:
-                cc = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-                parent = torch.empty(cap, dtype=torch.int32, device=dev)
-                off = torch.empty(cap, dtype=torch.int32, device=dev)
-                chd, up = self._strided[l, 0], self._strided[l, 1]
-                _l.check(L.urn_level_down_tables(self.coords[l].data_ptr(), n_dev, cap, self._hptr[l + 1], hcap,
-                                                 scratch.data_ptr(), sbytes, cc.data_ptr(), parent.data_ptr(),
-                                                 off.data_ptr(), cptr + 4 * (l + 1), chd.data_ptr(), cap,
-                                                 up.data_ptr(), cap, st), 'level_down_tables')
-                self.coords.append(cc); self.parent.append(parent); self.off.append(off)
-                self.chd.append(chd); self.up.append(up)
-            self.nbr.append(self._nbr_all[l])
-            spatials.append(sp)
-            sp = (sp + 1) // 2
-        # the 27-offset tables of every level in one launch
         nl = self.num_levels
         PA, IA = ctypes.c_void_p * nl, ctypes.c_int * nl
+        # counts: [n_l for each level] + [rules_l for each level]
+        self.counts = torch.zeros(2 * nl, dtype=torch.int32, device=dev)
+        cptr = self.counts.data_ptr()
+        self.row2site = torch.empty(cap, dtype=torch.int32, device=dev)
+        self._coords_all = torch.empty((nl, cap, 4), dtype=torch.int32, device=dev)
+        self.coords = [self._coords_all[l] for l in range(nl)]
+        self.ld = cap                      # leading dimension of every gather table
+        self.nbr, self.parent, self.off, self.chd, self.up = [], [], [], [], []
+        # strided tables are filled with -1 by one launch
+        if nl > 1:
+            self._strided = torch.empty((nl - 1, 2, 8, cap), dtype=torch.int32, device=dev)
+            _l.check(L.urn_fill_i32(self._strided.data_ptr(), self._strided.numel(), -1, st), 'fill')
+            self._links = torch.empty((nl - 1, 2, cap), dtype=torch.int32, device=dev)
+            self.parent = [self._links[l, 0] for l in range(nl - 1)]
+            self.off = [self._links[l, 1] for l in range(nl - 1)]
+            self.chd = [self._strided[l, 0] for l in range(nl - 1)]
+            self.up = [self._strided[l, 1] for l in range(nl - 1)]
+        self._nbr_all = torch.empty((nl, 27, cap), dtype=torch.int32, device=dev)
+        self.nbr = [self._nbr_all[l] for l in range(nl)]
+        spatials = []
+        sp = self.spatial
+        for l in range(nl):
+            spatials.append(sp)
+            sp = (sp + 1) // 2
+        if not per_level:
+            # every level straight from the input rows: four launches for the whole pyramid
+            sbytes = L.urn_levels_scratch_bytes(cap, nl)
+            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+            pad = [None]
+            _l.check(L.urn_sites_build_levels(
+                coords.data_ptr(), N, self.spatial, nl, PA(*self._hptr), hcap, scratch.data_ptr(), sbytes,
+                self.row2site.data_ptr(), PA(*[c.data_ptr() for c in self.coords]), cptr,
+                PA(*([t.data_ptr() for t in self.parent] + pad)), PA(*([t.data_ptr() for t in self.off] + pad)),
+                PA(*([t.data_ptr() for t in self.chd] + pad)), PA(*([t.data_ptr() for t in self.up] + pad)), cap, st),
+                'sites_build_levels')
+        else:
+            # level by level (the per-call C ABI: urn_sites_build, then urn_level_down_tables per level)
+            sbytes = L.urn_unique_scratch_bytes(cap)
+            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+            _l.check(L.urn_sites_build(coords.data_ptr(), N, self.spatial, self._hptr[0], hcap, scratch.data_ptr(),
+                                       sbytes, self.row2site.data_ptr(), self.coords[0].data_ptr(), cptr, st),
+                     'sites_build')
+            for l in range(nl - 1):
+                _l.check(L.urn_level_down_tables(self.coords[l].data_ptr(), cptr + 4 * l, cap, self._hptr[l + 1], hcap,
+                                                 scratch.data_ptr(), sbytes, self.coords[l + 1].data_ptr(),
+                                                 self.parent[l].data_ptr(), self.off[l].data_ptr(), cptr + 4 * (l + 1),
+                                                 self.chd[l].data_ptr(), cap, self.up[l].data_ptr(), cap, st),
+                         'level_down_tables')
+        # the 27-offset tables of every level in one launch
         _l.check(L.urn_rulebook_subm_multi(nl, PA(*[c.data_ptr() for c in self.coords]), PA(*[cptr + 4 * l for l in range(nl)]),
                                            cap, IA(*spatials), PA(*self._hptr), hcap, PA(*[t.data_ptr() for t in self.nbr]),
                                            cap, st), 'rulebook_subm_multi')
