@@ -81,6 +81,9 @@ def test_integer_phase_edges(dev):
     check_geometry(c, f, S, 3, dev)
     c1 = np.array([[3, 4, 5, 0]], np.int32)
     check_geometry(c1, np.ones((1, 1), np.float32), S, 2, dev)
+    # more levels than the multi-level entry points take (8): the per-level calls serve them
+    c9, f9 = cloud(5, 512, 300, 1, 3)
+    check_geometry(c9, f9, 512, 9, dev)
 
 
 def test_integer_phase_full_size(dev):

@@ -8,6 +8,9 @@ import torch
 from . import lib as _l
 
 
+MAX_MULTI = 8      # URN_GEO_MAX_LEVELS / URN_RB_MAX_LEVELS of the library
+
+
 class SparseGeometry:
     """Active sites, hash tables and gather tables of every level of one forward.
 
@@ -70,7 +73,7 @@ class SparseGeometry:
         for l in range(nl):
             spatials.append(sp)
             sp = (sp + 1) // 2
-        if not per_level:
+        if not per_level and nl <= MAX_MULTI:
             # every level straight from the input rows: four launches for the whole pyramid
             sbytes = L.urn_levels_scratch_bytes(cap, nl)
             scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
@@ -94,10 +97,15 @@ class SparseGeometry:
                                                  self.parent[l].data_ptr(), self.off[l].data_ptr(), cptr + 4 * (l + 1),
                                                  self.chd[l].data_ptr(), cap, self.up[l].data_ptr(), cap, st),
                          'level_down_tables')
-        # the 27-offset tables of every level in one launch
-        _l.check(L.urn_rulebook_subm_multi(nl, PA(*[c.data_ptr() for c in self.coords]), PA(*[cptr + 4 * l for l in range(nl)]),
-                                           cap, IA(*spatials), PA(*self._hptr), hcap, PA(*[t.data_ptr() for t in self.nbr]),
-                                           cap, st), 'rulebook_subm_multi')
+        # the 27-offset tables of every level in one launch (the multi-level entry points take up to MAX_MULTI levels)
+        if nl <= MAX_MULTI:
+            _l.check(L.urn_rulebook_subm_multi(nl, PA(*[c.data_ptr() for c in self.coords]), PA(*[cptr + 4 * l for l in range(nl)]),
+                                               cap, IA(*spatials), PA(*self._hptr), hcap, PA(*[t.data_ptr() for t in self.nbr]),
+                                               cap, st), 'rulebook_subm_multi')
+        else:
+            for l in range(nl):
+                _l.check(L.urn_rulebook_subm(self.coords[l].data_ptr(), cptr + 4 * l, cap, spatials[l], self._hptr[l], hcap,
+                                             self.nbr[l].data_ptr(), cap, None, st), 'rulebook_subm')
         self._scratch = scratch
         self._rules = None
         self.n = None
