@@ -96,8 +96,9 @@ class SegmentationLoss(torch.nn.modules.loss._Loss):
                 lab = label[i] if label[i].dtype == torch.float32 else label[i].float()
                 w = None if weight is None else weight[i]
                 loss_i, out = so.SegmentationCEFunction.apply(segmentation[i], d, lab, w)
-                total_loss = total_loss + loss_i
-                total_acc = total_acc + out[1]
+                # (the first entry is taken as it is: "0 + tensor" would be one more launch on the device)
+                total_loss = loss_i if i == 0 else total_loss + loss_i
+                total_acc = out[1] if i == 0 else total_acc + out[1]
                 continue
             batch_ids = data[i][:, -2]
             ids, inv = torch.unique(batch_ids, return_inverse=True)
