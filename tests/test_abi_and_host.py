@@ -30,6 +30,19 @@ def test_library_exports_every_declared_symbol():
     assert L.urn_unique_scratch_bytes(1000) > 4000 and L.urn_bn_scratch_bytes(16) > 0
 
 
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md is the reference-side binding text: small, and it names every function the header declares."""
+    path = os.path.join(ROOT, 'INTEGRATION.md')
+    assert os.path.getsize(path) < 50 * 1024, 'INTEGRATION.md is %d bytes' % os.path.getsize(path)
+    doc = open(path).read()
+    hdr = open(os.path.join(ROOT, 'include', 'uresnet_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(urn_[a-z0-9_]+)\s*\(', hdr))
+    named = set(re.findall(r'`(urn_[a-z0-9_]+)`', doc))
+    assert declared <= named, sorted(declared - named)
+    assert 'import uresnet_pytorch_amd.scn as scn' in doc and 'ctypes.CDLL' in doc
+
+
 def test_product_path_has_no_cpu_fallback():
     from uresnet_pytorch_amd.models import SparseUResNet
     fl = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=2, SPATIAL_SIZE=16, NUM_CLASS=3)
