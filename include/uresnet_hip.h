@@ -108,6 +108,18 @@ int urn_down_tables(const int32_t *parent, const int32_t *off, const int32_t *n_
 
 int urn_fill_i32(int32_t *p, int64_t n, int32_t v, void *stream);
 
+/* Compacted rule lists ("pair lists") of gather tables, the form the MFMA kernels consume (the rulebook of
+ * scn.SubmanifoldConvolution / Convolution / Deconvolution, reference uresnet_sparse.py:21-22, grouped per tile of
+ * `tile` (32, 64 or 128) output rows): per tile [0] = number of blocks, then the table row t of every block, then 16 words
+ * per block, word = input row | (row inside the tile << 24); blocks are ordered by t, a table row's last block is padded
+ * with words (tile << 24) (gather row 0, discard).  urn_pairs_bytes = size of one list; urn_pairs_build compacts n_tables
+ * tables (host arrays of n_tables entries; n_dev[i] = device int32 row count or NULL = n_cap[i]) in one launch.
+ * Deterministic: the list depends on the table only. */
+int64_t urn_pairs_bytes(int64_t n_cap, int K, int tile);
+int urn_pairs_build(int n_tables, const int32_t *const *tbl, const int64_t *ld, const int *K,
+                    const int32_t *const *n_dev, const int64_t *n_cap, const int *tile, int32_t *const *pairs,
+                    void *stream);
+
 /* -------------------------------------------------------------------- float phase
  * Gather convolution, the one arithmetic kernel behind SubmanifoldConvolution,
  * Convolution(k2,s2) and Deconvolution(k2,s2) forward and input-gradient:
@@ -206,6 +218,13 @@ typedef struct {
     /* Row strides (in floats) of x and y when they are column blocks of wider row matrices -- the halves of a channel
      * concat: 0 = dense (cin / cout).  res, e_x and the statistics slabs are always dense.  2-D tile kernel only. */
     int64_t ldx, ldy;
+    /* Compacted rule list of `tbl` (urn_pairs_build) and its tile size (32, 64 or 128 rows): the call then runs on the
+     * pair-list kernel -- per tile of output rows and table row, the valid (input row, output row) pairs packed into
+     * blocks of 16, so that the matrix pipe multiplies rules, not (16-row block, offset) products that are mostly
+     * absent neighbours.  pairs == NULL with pairs_tile != 0 and K == 1 declares tbl the identity (a 1x1 convolution:
+     * scn.NetworkInNetwork).  pairs_tile == 0: the dense-table kernels.  fp32 operands only. */
+    const int32_t *pairs;
+    int pairs_tile;
 } urn_gconv_args;
 int64_t urn_gconv_part_bytes(int64_t n_out, int cout);
 int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);
@@ -288,6 +307,11 @@ int64_t urn_net_running_count(const urn_net *net);
 int urn_net_num_tensors(const urn_net *net);
 int urn_net_tensor(const urn_net *net, int i, int64_t *off, int64_t *numel);
 int64_t urn_net_workspace_bytes(urn_net *net, int num_levels, const int64_t *n, int64_t n_rows, int with_backward);
+/* Optional, before a forward: the compacted rule lists (urn_pairs_build) of that forward's tables -- arrays of
+ * num_levels host pointers (the last entry of chd/up unused; an array may be NULL) and, per level, their tile sizes.  They apply to the
+ * NEXT urn_net_forward (and its backward) only; without them the executor runs on the dense tables. */
+int urn_net_set_pairs(urn_net *net, int num_levels, const void *const *nbr_pairs, const void *const *chd_pairs,
+                      const void *const *up_pairs, const int *tile_nbr, const int *tile_chd, const int *tile_up);
 int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const int64_t *n, const void *const *nbr,
                     const void *const *chd, const void *const *up, const int32_t *row2site, int64_t n_rows,
                     const float *params, float *running, const float *site_feats, void *ws, int64_t ws_bytes,

@@ -1,0 +1,230 @@
+"""GPU parity tests of the compacted rule lists ("pair lists") and of the gather convolution that walks them
+(uresnet_pytorch_amd/csrc/urn_gconv_pairs.hip), through the C ABI, against the CPU oracle.
+
+Lists: bit-exact against a numpy restatement of the layout documented in include/uresnet_hip.h.
+Convolutions: forward, input gradient and weight gradient within 1e-5 relative (norm-wise, the tolerance of
+BASELINE.json's north_star) -- on small clouds for every channel shape, and on the REAL BASELINE configs[2] geometry
+(512^3, 50,000 voxels, 5 levels) for every (level, cin, cout) the network runs there.  Results are bitwise
+reproducible from run to run (no float atomics across waves)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_oracle as orc
+from uresnet_pytorch_amd.iotools.synthetic import generate_event, make_sparse_blob
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from uresnet_pytorch_amd import lib
+    lib.load()
+    return torch.device('cuda:0')
+
+
+def cloud(seed, S, n, nbatch):
+    cs = []
+    for b in range(nbatch):
+        c, _, _ = generate_event(seed * 10 + b, S, n)
+        cs.append(np.concatenate([c, np.full((len(c), 1), b, np.int32)], 1))
+    c = np.ascontiguousarray(np.concatenate(cs, 0), np.int32)
+    f = np.random.default_rng(seed).normal(size=(len(c), 1)).astype(np.float32)
+    return c, f
+
+
+def pairs_ref(tbl, n, T):
+    """numpy restatement of the list layout: per tile [nblk | 15 unused | t of every block | 16 words per block]"""
+    K = tbl.shape[0]
+    maxb = K * (T // 16)
+    out = []
+    for tile in range((n + T - 1) // T):
+        rows = np.arange(tile * T, min(n, (tile + 1) * T))
+        ts, words = [], []
+        for t in range(K):
+            v = tbl[t, rows]
+            ok = v >= 0
+            w = (v[ok].astype(np.int64) | ((rows[ok] - tile * T).astype(np.int64) << 24))
+            pad = (-len(w)) % 16
+            w = np.concatenate([w, np.full(pad, T << 24, np.int64)])
+            ts += [t] * (len(w) // 16)
+            words.append(w)
+        out.append((len(ts), np.array(ts, np.int64), np.concatenate(words) if words else np.zeros(0, np.int64), maxb))
+    return out
+
+
+def check_pairs(lst, tile, tbl, n, K):
+    maxb = K * (tile // 16)
+    words = 16 + maxb + maxb * 16
+    got = lst.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    for i, (nb, ts, w, _) in enumerate(pairs_ref(tbl, n, tile)):
+        base = i * words
+        assert got[base] == nb, (i, got[base], nb)
+        assert np.array_equal(got[base + 16:base + 16 + nb], ts)
+        assert np.array_equal(got[base + 16 + maxb:base + 16 + maxb + 16 * nb], w & 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize('seed,S,n,nb,L', [(1, 24, 400, 2, 3), (2, 64, 3000, 3, 4), (3, 16, 50, 1, 2), (4, 8, 1, 1, 2)])
+def test_pair_lists_bit_exact(dev, seed, S, n, nb, L):
+    from uresnet_pytorch_amd import sparse_ops as so
+    c, f = cloud(seed, S, n, nb)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, L)
+    ref = orc.Geometry(c, f, S, L)
+    for l in range(L):
+        lst, tile = geo.pairs['nbr'][l]
+        check_pairs(lst, tile, ref.nbr[l], ref.n[l], 27)
+        if l + 1 < L:
+            lst, tile = geo.pairs['chd'][l]
+            check_pairs(lst, tile, ref.chd[l], ref.n[l + 1], 8)
+            lst, tile = geo.pairs['up'][l]
+            check_pairs(lst, tile, ref.up[l], ref.n[l], 8)
+
+
+def run_conv(dev, geo_t, ref_t, ref_inv, n_out, n_in, cin, cout, pairs_f, pairs_b, flip_b, ld, with_res, seed, tbl_b=None,
+             check_dw=True):
+    """forward + both gradients of one gather convolution on the pair-list kernel vs the oracle; returns y, dx for
+    determinism checks"""
+    from uresnet_pytorch_amd import sparse_ops as so
+    K = ref_t.shape[0]
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    W = (rng.normal(size=(K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    res = rng.normal(size=(n_out, cout)).astype(np.float32) if with_res else None
+    dy = rng.normal(size=(n_out, cout)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    Wt = torch.from_numpy(W).to(dev).requires_grad_(True)
+    rt = torch.from_numpy(res).to(dev) if with_res else None
+    y = so.GConvFunction.apply(xt, Wt, rt, geo_t, geo_t if tbl_b is None else tbl_b, flip_b, ld, n_out, n_in, pairs_f, pairs_b)
+    y.backward(torch.from_numpy(dy).to(dev))
+    y_ref = orc.conv_fwd(x, W, ref_t) + (res if with_res else 0.0)
+    dx_ref, dW_ref = orc.conv_bwd(x, W, ref_t, dy, ref_inv)
+    ey, ex = rel(y.detach().cpu().numpy(), y_ref), rel(xt.grad.cpu().numpy(), dx_ref)
+    assert ey < TOL and ex < TOL, (cin, cout, ey, ex)
+    if check_dw:
+        ew = rel(Wt.grad.cpu().numpy(), dW_ref)
+        assert ew < TOL, (cin, cout, ew)
+    return y.detach(), xt.grad.detach(), Wt.grad.detach()
+
+
+SHAPES = [(16, 16), (16, 32), (32, 16), (32, 32), (48, 48), (96, 48), (64, 64), (128, 64), (64, 128), (80, 80), (160, 80),
+          (80, 160), (64, 80), (192, 96), (224, 224)]
+
+
+@pytest.mark.parametrize('cin,cout', SHAPES)
+def test_pairs_subm_conv(dev, cin, cout):
+    from uresnet_pytorch_amd import sparse_ops as so
+    S = 32
+    c, f = cloud(7, S, 1500, 2)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
+    ref = orc.Geometry(c, f, S, 1)
+    n = ref.n[0]
+    p = geo.pairs['nbr'][0]
+    a = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
+    b = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), 'forward / input gradient not bitwise reproducible'
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 32), (64, 80), (48, 32), (32, 48)])
+def test_pairs_strided_and_nin(dev, cin, cout):
+    from uresnet_pytorch_amd import sparse_ops as so
+    S = 32
+    c, f = cloud(8, S, 1500, 2)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 2)
+    ref = orc.Geometry(c, f, S, 2)
+    nf, nc = ref.n
+    # Convolution(k2, s2): fine -> coarse; its input gradient walks the fine<-parent list
+    run_conv(dev, geo.chd[0], ref.chd[0], ref.chd_inv[0], nc, nf, cin, cout, geo.pairs['chd'][0], geo.pairs['up'][0], 0,
+             geo.ld, False, 1, tbl_b=geo.up[0])
+    # Deconvolution(k2, s2): coarse -> fine
+    run_conv(dev, geo.up[0], ref.up[0], ref.up_inv[0], nf, nc, cout, cin, geo.pairs['up'][0], geo.pairs['chd'][0], 0,
+             geo.ld, False, 2, tbl_b=geo.chd[0])
+    # NetworkInNetwork: the identity list
+    ident_ref = np.arange(nf, dtype=np.int32)[None, :]
+    run_conv(dev, geo.nbr[0][13:14], ident_ref, ident_ref, nf, nf, cin, cout, so.IDENT_PAIRS, so.IDENT_PAIRS, 0, geo.ld,
+             False, 3)
+
+
+@pytest.fixture(scope='module')
+def cfg3(dev):
+    """BASELINE configs[2] geometry: seed-0 event, 512^3, 50,000 voxels, 5 levels"""
+    from uresnet_pytorch_amd import sparse_ops as so
+    blob = make_sparse_blob([0], 512, 50000)
+    c = np.ascontiguousarray(blob['data'][:, :4].astype(np.int32))
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), 512, 5)
+    ref = orc.Geometry(c, blob['data'][:, 4:5], 512, 5)
+    assert geo.n == ref.n
+    return geo, ref
+
+
+@pytest.mark.parametrize('level', [0, 1, 2, 3, 4])
+def test_conv_ops_on_cfg3_geometry(dev, cfg3, level):
+    """every convolution shape the cfg3 network runs at this level (uf 16: P = 16 (level + 1)), on the real geometry:
+    SubM3 P->P and 2P->P, NiN 2P->P, Convolution P->P', Deconvolution P'->P -- forward, dX, dW <= 1e-5 vs the oracle"""
+    from uresnet_pytorch_amd import sparse_ops as so
+    geo, ref = cfg3
+    l, P = level, 16 * (level + 1)
+    n = ref.n[l]
+    p = geo.pairs['nbr'][l]
+    shapes = [(P, P)] + ([(2 * P, P)] if l < 4 else [])
+    for cin, cout in shapes:
+        run_conv(dev, geo.nbr[l], ref.nbr[l], ref.nbr_inv[l], n, n, cin, cout, p, p, 1, geo.ld, True, 10 * l + cin)
+    if l < 4:
+        ident_ref = np.arange(n, dtype=np.int32)[None, :]
+        run_conv(dev, geo.nbr[l][13:14], ident_ref, ident_ref, n, n, 2 * P, P, so.IDENT_PAIRS, so.IDENT_PAIRS, 0, geo.ld, False, 5)
+        nc, P2 = ref.n[l + 1], P + 16
+        run_conv(dev, geo.chd[l], ref.chd[l], ref.chd_inv[l], nc, n, P, P2, geo.pairs['chd'][l], geo.pairs['up'][l], 0,
+                 geo.ld, False, 6, tbl_b=geo.up[l])
+        run_conv(dev, geo.up[l], ref.up[l], ref.up_inv[l], n, nc, P2, P, geo.pairs['up'][l], geo.pairs['chd'][l], 0,
+                 geo.ld, False, 7, tbl_b=geo.chd[l])
+
+
+def test_pairs_fused_epilogues_match_tile_kernel(dev):
+    """The fused pieces (input BatchNorm+ReLU fold, column statistics, BatchNorm-backward reduce, strided output) of the
+    pair-list kernel against the same call on the dense-table kernel (which tests/test_gpu_sparse.py pins to the oracle):
+    y within 1e-6, statistics slabs (fp64 sums) within 1e-9 relative."""
+    from uresnet_pytorch_amd import lib as _l, sparse_ops as so
+    L = _l.load()
+    S = 32
+    c, f = cloud(9, S, 2000, 2)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
+    n = geo.n[0]
+    g = torch.Generator(device='cpu').manual_seed(0)
+    for cin, cout, epi in [(32, 32, 1), (64, 32, 1), (32, 64, 2), (16, 16, 2), (96, 48, 1)]:
+        x = torch.randn(n, cin, generator=g).to(dev)
+        wt = (torch.randn(27, cout, cin, generator=g) / (27 * cin) ** 0.5).to(dev)
+        sc = (torch.rand(cin, generator=g) + 0.5).to(dev); sh = (torch.randn(cin, generator=g) * 0.3).to(dev)
+        res = torch.randn(n, cout, generator=g).to(dev)
+        ex = torch.randn(n, cout, generator=g).to(dev)
+        esc = (torch.rand(cout, generator=g) + 0.5).to(dev); esh = (torch.randn(cout, generator=g) * 0.3).to(dev)
+        emu = torch.randn(cout, generator=g).to(dev); eis = (torch.rand(cout, generator=g) + 0.5).to(dev)
+        outs = []
+        for use_pairs in (False, True):
+            ldy = cout + 16
+            y = torch.zeros(n, ldy, device=dev)
+            part = torch.zeros(L.urn_gconv_part_bytes(n, cout) // 8, dtype=torch.float64, device=dev)
+            a = _l.GConvArgs()
+            a.x = x.data_ptr(); a.wt = wt.data_ptr(); a.tbl = geo.nbr[0].data_ptr(); a.ld = geo.ld; a.K = 27; a.flip = 0
+            a.n_out = n; a.cin = cin; a.cout = cout; a.res = res.data_ptr(); a.y = y.data_ptr(); a.ldy = ldy
+            a.xf_scale = sc.data_ptr(); a.xf_shift = sh.data_ptr()
+            a.epilogue = epi; a.part = part.data_ptr()
+            if epi == 2:
+                a.e_x = ex.data_ptr(); a.e_scale = esc.data_ptr(); a.e_shift = esh.data_ptr()
+                a.e_mean = emu.data_ptr(); a.e_invstd = eis.data_ptr()
+            if use_pairs:
+                a.pairs = geo.pairs['nbr'][0][0].data_ptr(); a.pairs_tile = geo.pairs['nbr'][0][1]
+            npart = ctypes.c_int(0)
+            _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), ctypes.byref(npart), _l.stream()), 'gconv_fwd_ex')
+            sums = part[:npart.value * 2 * cout].reshape(npart.value, 2, cout).sum(0)
+            outs.append((y.cpu().numpy(), sums.cpu().numpy()))
+        assert rel(outs[1][0], outs[0][0]) < 1e-6, (cin, cout, epi)
+        assert np.array_equal(outs[1][0][:, cout:], np.zeros((n, 16), np.float32)), 'wrote outside its column block'
+        assert rel(outs[1][1], outs[0][1]) < 1e-6, (cin, cout, epi, outs[1][1][:, :4], outs[0][1][:, :4])

@@ -252,13 +252,17 @@ struct Pick { int mb, nb; };
 
 // tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
 // before the column tile is widened
-extern long g_lds_min_wgs;
 int g_opt_precision = 0;   // default MFMA operand precision of the gather convolutions: 0 fp32, 1 bf16, 2 fp16
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
 static int g_opt_fin_in_kernel = 0;
 static int g_opt_pipe = 0;
-static int g_opt_kernel = 6;   // 6 = 2-D workgroup tile (urn_gconv_tile.hip), 4 = 64x16 LDS tile (urn_gconv_lds.hip), 5 = LDS-DMA ring, 3 = register gather
+static int g_opt_kernel = 7;   // 7 = compacted rule lists when the call carries them (urn_gconv_pairs.hip), else the 2-D tile; 6 = 2-D workgroup tile (urn_gconv_tile.hip); 3 = register gather (fallback for shapes without a tile instantiation)
+extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs;
+// which calls that carry a pair list run on the pair-list kernel (measured per shape on the cfg3 geometry, tools/bench_pairs.py:
+// it wins for the strided pair and the narrow levels; the wide, small levels are faster on the LDS-staged 2-D tile kernel):
+// K == 8, or K == 27 with cin <= g_pairs_max_cin and cout <= g_pairs_max_cout; K == 1 only when g_pairs_nin is set
+static int g_pairs_max_cin = 999, g_pairs_max_cout = 999, g_pairs_nin = 0;
 static long g_opt_min_waves = 8192;
 
 extern "C" int urn_set_option(const char *key, int64_t value)
@@ -267,7 +271,14 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "gconv_pipe")) { g_opt_pipe = value != 0; return URN_OK; }
     if (!strcmp(key, "gconv_min_waves")) { g_opt_min_waves = value; return URN_OK; }
     if (!strcmp(key, "gconv_kernel")) { g_opt_kernel = (int)value; return URN_OK; }
-    if (!strcmp(key, "gconv_lds_min_wgs")) { g_lds_min_wgs = value; return URN_OK; }
+    if (!strcmp(key, "pairs_waves")) { g_pairs_waves = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_max_cin")) { g_pairs_max_cin = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_max_cout")) { g_pairs_max_cout = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_nin")) { g_pairs_nin = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_nc")) { g_pairs_nc = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_cbg")) { g_pairs_cbg = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_wgs")) { g_pairs_wgs = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_split")) { g_pairs_split = (int)value; return URN_OK; }
     if (!strcmp(key, "gconv_dbg")) { g_opt_dbg = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_rb")) { g_tile_rb = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_cb")) { g_tile_cb = (int)value; return URN_OK; }
@@ -367,7 +378,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
         return URN_OK;
     }
     static const bool env_once = [] {
-        if (const char *e = getenv("URN_GCONV_KERNEL")) g_opt_kernel = atoi(e);   // A/B switch: 3 register, 4 LDS, 5 LDS-DMA
+        if (const char *e = getenv("URN_GCONV_KERNEL")) g_opt_kernel = atoi(e);   // A/B switch: 7 pair lists, 6 2-D tile, 3 register
         return true;
     }();
     (void)env_once;
@@ -422,7 +433,22 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
                       "do not cover ld=%ld x ldx=%ld", (long)u->ld, a.ldx);
         return URN_EUNSUPPORTED;
     }
-    if (off32_ok && ((g_opt_kernel == 6 && !in_kernel) || sums_mode || a.prec || strided)) {
+    // compacted rule lists: the call carries the list of its table (or asks for the identity list of a 1x1 convolution)
+    const bool pairs_shape = u->K == 8 || (u->K == 1 && g_pairs_nin) || (u->K > 8 && u->cin <= g_pairs_max_cin && u->cout <= g_pairs_max_cout);
+    if (g_opt_kernel >= 7 && u->pairs_tile != 0 && a.prec == 0 && !in_kernel && pairs_shape && (u->pairs != nullptr || u->K == 1)) {
+        a.pairs = u->pairs; a.p_tile = u->pairs_tile;
+        const int npp = urn_gconv_pairs_launch(a, u->n_out, st);
+        if (npp > 0) {
+            if (prof) urn_prof_end(st);
+            const int np = u->part_slots > 0 ? u->part_slots : npp;
+            if (n_tiles) *n_tiles = np;
+            URN_LAUNCH_CHECK();
+            if (want_fin) return finalize_launches(u, np, stream);
+            return URN_OK;
+        }
+        a.pairs = nullptr; a.p_tile = 0;
+    }
+    if (off32_ok && ((g_opt_kernel >= 6 && !in_kernel) || sums_mode || a.prec || strided)) {
         const int np6 = urn_gconv_tile_launch(a, ks, u->n_out, st);
         if (np6 > 0) {
             if (prof) urn_prof_end(st);
@@ -442,15 +468,6 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
             urn_set_error("urn_gconv_fwd_ex: accumulated statistics need the 2-D tile kernel (cin=%d cout=%d has none)", u->cin, u->cout);
             return URN_EUNSUPPORTED;
         }
-    }
-    if ((g_opt_kernel == 5 && urn_gconv_dma_launch(a, ks, u->n_out, st)) ||
-        (g_opt_kernel >= 4 && urn_gconv_lds_launch(a, ks, u->n_out, st))) {
-        if (prof) urn_prof_end(st);
-        const int np = (int)((u->n_out + 63) / 64);   // one partial row per 64-row workgroup
-        if (n_tiles) *n_tiles = np;
-        URN_LAUNCH_CHECK();
-        if (want_fin && !in_kernel) return finalize_launches(u, np, stream);
-        return URN_OK;
     }
     a.sync_word = nullptr;   // the register-gather kernel below has no in-kernel finalize
     switch (ks) {

@@ -35,12 +35,15 @@ struct GArgs {
     float *xs_mean, *xs_invstd, *xs_scale, *xs_shift, *xs_rm, *xs_rv;
     long ldx, ldy;   // row strides of x and y in floats (cin / cout unless a tensor is a column block of a wider matrix)
     int prec;  // MFMA operand precision: 0 fp32, 1 bf16, 2 fp16 (urn_gconv_args.precision / option "gconv_precision")
+    // compacted rule lists (urn_gconv_pairs.hip): list of the table (NULL with p_tile != 0 = identity table of a 1x1 conv),
+    // rows per tile (64 / 128), split of a tile's block list over waves, columns per workgroup
+    const int *pairs;
+    int p_tile, p_split, p_cw;
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };
 
-// LDS-staged variant (urn_gconv_lds.hip): returns false when it has no instantiation for the shape
-bool urn_gconv_lds_launch(const GArgs &a, int ks, long n_out, hipStream_t st);
+#define URN_PAIRS_HDR 16   // int32 words in front of a tile's block list ([0] = number of blocks)
+// compacted rule lists (urn_gconv_pairs.hip): returns the number of partial rows (tiles), 0 = no instantiation
+int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st);
 // 2-D workgroup tile (urn_gconv_tile.hip): returns the number of partial rows, 0 = no instantiation
 int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st);
-// LDS-DMA ring variant (urn_gconv_dma.hip)
-bool urn_gconv_dma_launch(const GArgs &a, int ks, long n_out, hipStream_t st);

@@ -1,0 +1,390 @@
+// Gather convolution over COMPACTED rule lists ("pair lists"), wave-autonomous, no barriers in the offset loop.
+//
+// Why: the 2-D tile kernel (urn_gconv_tile.hip) is output-stationary over 16-row blocks and executes every offset that
+// is active for ANY row of the block: on the cfg3 geometry that is 2.4-3.4x the rules that exist (R/N = 4.4-10 of 27
+// offsets, but a 16-row block touches 14-24 of them), and its offset step is one workgroup barrier per 4-16 MFMAs.
+// Here the rules of a tile of T output rows are compacted per table row t (= filter offset) into dense blocks of 16
+// (in_row, out_row) pairs by the integer phase (k_pairs_build below): 1.2-1.6x the rules instead of 2.4-3.4x, and for
+// the strided pair (one parent per fine row) 1.4-2x instead of 7x.
+//
+// One wave owns 16*NC output columns of a tile and a contiguous share [b0, b1) of the tile's block list (the list is
+// split G ways so that deep, small levels still fill the chip).  Per block it gathers the 16 input rows straight into
+// MFMA A fragments (global -> registers, 64 B per row and 16-channel group), keeps the weight fragments of the current
+// offset in registers (reloaded only when the offset changes), runs v_mfma_f32_16x16x4_f32 and adds the 16x16 result
+// into its PRIVATE fp32 slab in LDS with ds_add_f32 at the rows' positions in the tile.  A wave's adds execute in
+// program order and no two waves share a slab element, so the sum order is fixed by the list: results are bitwise
+// reproducible.  After one workgroup barrier the G partial slabs are summed in order g = 0..G-1 and the epilogue
+// (residual, BatchNorm statistics or BatchNorm-backward reduce, exactly as in the tile kernel) writes y.
+//
+// Padding pairs of a partly filled block gather row 0 and add into a trash row (index T) of the slab: no masks.
+#include "urn_common.h"
+#include "urn_gconv_int.h"
+#include "urn_prof.h"
+#include <string.h>
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+static __host__ __device__ inline long pairs_tile_words(int K, int T)
+{
+    const long maxb = (long)K * (T / 16);
+    return URN_PAIRS_HDR + maxb + maxb * 16;
+}
+
+// ------------------------------------------------------------------------------------------------ list builder
+#define URN_PAIRS_MAX_TABLES 16
+struct PairsDesc { const int *tbl; long ld; int K; const int *n_dev; long n_cap; int T; int *out; int ntiles; };
+struct PairsDescs { int n; PairsDesc d[URN_PAIRS_MAX_TABLES]; };
+
+__global__ __launch_bounds__(128) void k_pairs_build(PairsDescs ds)
+{
+    const PairsDesc d = ds.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.ntiles) return;
+    const int T = d.T, K = d.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (T <= 64 && wave) return;   // one wave per tile of 32 / 64 rows (no barrier is executed for them)
+    __shared__ int s_cnt[2];
+    const long n_out = d.n_dev ? (long)*d.n_dev : d.n_cap;
+    const long row = (long)blockIdx.x * T + tid;
+    const long maxb = (long)K * (T / 16);
+    int *out = d.out + (long)blockIdx.x * pairs_tile_words(K, T);
+    int *out_t = out + URN_PAIRS_HDR, *out_p = out_t + maxb;
+    int nb = 0;
+    for (int t = 0; t < K; ++t) {
+        const int v = (tid < T && row < n_out) ? d.tbl[(long)t * d.ld + row] : -1;
+        const unsigned long long b = __ballot(v >= 0);
+        const int my = __popcll(b & ((1ull << lane) - 1ull)), wcnt = __popcll(b);
+        int base = 0, total = wcnt;
+        if (T == 128) {
+            if (lane == 0) s_cnt[wave] = wcnt;
+            __syncthreads();
+            base = wave ? s_cnt[0] : 0;
+            total = s_cnt[0] + s_cnt[1];
+            __syncthreads();
+        }
+        if (v >= 0) out_p[(long)nb * 16 + base + my] = v | (tid << 24);
+        const int nblk_t = (total + 15) >> 4;
+        if (tid < nblk_t * 16 - total) out_p[(long)nb * 16 + total + tid] = T << 24;   // padding: gather row 0, add into the trash row
+        if (tid < nblk_t) out_t[nb + tid] = t;
+        nb += nblk_t;
+    }
+    if (tid == 0) out[0] = nb;
+}
+
+extern "C" int64_t urn_pairs_bytes(int64_t n_cap, int K, int tile)
+{
+    if (n_cap < 0 || K <= 0 || (tile != 32 && tile != 64 && tile != 128)) return -1;
+    const int64_t ntiles = (n_cap + tile - 1) / tile;
+    return (ntiles > 0 ? ntiles : 1) * pairs_tile_words(K, tile) * 4;
+}
+
+extern "C" int urn_pairs_build(int n_tables, const int32_t *const *tbl, const int64_t *ld, const int *K,
+                               const int32_t *const *n_dev, const int64_t *n_cap, const int *tile, int32_t *const *pairs,
+                               void *stream)
+{
+    URN_CHECK_ARG(n_tables >= 0 && (n_tables == 0 || (tbl && ld && K && n_cap && tile && pairs)), "null pointer");
+    for (int base = 0; base < n_tables; base += URN_PAIRS_MAX_TABLES) {
+        PairsDescs ds;
+        ds.n = n_tables - base < URN_PAIRS_MAX_TABLES ? n_tables - base : URN_PAIRS_MAX_TABLES;
+        int max_tiles = 0;
+        for (int i = 0; i < ds.n; ++i) {
+            const int j = base + i;
+            URN_CHECK_ARG(tbl[j] && pairs[j] && K[j] > 0 && K[j] <= 27 && (tile[j] == 32 || tile[j] == 64 || tile[j] == 128) && ld[j] >= n_cap[j] &&
+                          n_cap[j] >= 0 && n_cap[j] < (1 << 24), "bad table (K <= 27, tile 32, 64 or 128, fewer than 2^24 rows)");
+            PairsDesc &d = ds.d[i];
+            d.tbl = tbl[j]; d.ld = (long)ld[j]; d.K = K[j]; d.n_dev = n_dev ? n_dev[j] : nullptr; d.n_cap = (long)n_cap[j];
+            d.T = tile[j]; d.out = pairs[j]; d.ntiles = (int)((n_cap[j] + tile[j] - 1) / tile[j]);
+            if (d.ntiles > max_tiles) max_tiles = d.ntiles;
+        }
+        if (max_tiles == 0) continue;
+        hipLaunchKernelGGL(k_pairs_build, dim3(max_tiles, ds.n), dim3(128), 0, (hipStream_t)stream, ds);
+        URN_LAUNCH_CHECK();
+    }
+    return URN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ convolution
+// KC: 16-channel groups per contraction chunk (cin = 16 * KC * nch); NC: 16-column blocks per wave; XF: rows are used as
+// relu(x * scale + shift) (folded BatchNorm+ReLU of the input)
+template <int KC, int NC, int XF>
+__global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_pairs(GArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = g.p_tile, G = g.p_split;
+    const int cin = g.cin, cout = g.cout, K = g.K;
+    const int nch = cin / (16 * KC);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+    const int r = lane & 15, q = lane >> 4;
+    const int cw = g.p_cw;                         // columns of this workgroup (blockIdx.y selects the column range)
+    const int CBG = cw / (16 * NC);
+    const int cg = wave % CBG, gi = wave / CBG;
+    const int colw = blockIdx.y * cw;              // first column of the workgroup
+    const int lcol0 = cg * 16 * NC;                // first column of the wave inside the workgroup's range
+    const int col0 = colw + lcol0;
+    const int LDW = cw + 4;                        // +4 floats: consecutive rows start 16 B apart in the bank row
+    // LDS: [2][cin] folded affine | G slabs of (T + 1) x cw | [2][G][cw] doubles (epilogue reduction)
+    float *s_xf = smem;
+    float *s_slab = smem + (XF ? 2 * cin : 0);
+    const long slab_words = (long)(T + 1) * LDW;
+    double *s_p = (double *)(s_slab + (((long)G * slab_words + 1) & ~1L));
+
+    const long n_out = g.n_dev ? (long)*g.n_dev : g.n_cap;
+    // XCD-aware tile assignment (workgroups are dealt round-robin to the 8 XCDs): XCD x gets a contiguous range of tiles
+    unsigned tile = blockIdx.x;
+    {
+        const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        tile = xcd * xq + (xcd < xr ? xcd : xr) + slot;
+    }
+    const long row0 = (long)tile * T;
+    const int rows_here = (int)(n_out - row0 < (long)T ? n_out - row0 : (long)T);
+    if (rows_here <= 0) return;   // workgroup-uniform
+
+    const bool ident = g.pairs == nullptr;   // 1x1 convolution on the identity table: blocks of 16 consecutive rows
+    const long maxb = (long)K * (T / 16);
+    const int *hdr = ident ? nullptr : g.pairs + (long)tile * pairs_tile_words(K, T);
+    const int *blk_t = hdr + URN_PAIRS_HDR;
+    const int *blk_p = blk_t + maxb;
+    const int nblk = ident ? (rows_here + 15) >> 4 : hdr[0];
+    const int b0 = nblk * gi / G, b1 = nblk * (gi + 1) / G;   // nblk <= 27 * 8, G <= 16
+
+    if constexpr (XF != 0) {
+        if (g.xs_sums[0] != nullptr) {
+            // statistics of the input rows accumulated by the producers: same arithmetic as k_bn_finalize_fwd_f
+            const bool keep = blockIdx.x == 0 && blockIdx.y == 0;
+            const double inv_n = g.xs_n > 0 ? 1.0 / (double)g.xs_n : 0.0;
+            for (int e = tid; e < cin; e += nthreads) {
+                const int sl = e >= g.xs_split ? 1 : 0;
+                const int ch = sl ? e - g.xs_split : e;
+                const double *p = g.xs_sums[sl] + ch;
+                const int ld = g.xs_ld[sl];
+                double v0 = 0.0, v1 = 0.0;
+                for (int k = 0; k < g.xs_slots; ++k) { v0 += p[(long)(2 * k) * ld]; v1 += p[(long)(2 * k + 1) * ld]; }
+                const double mu = v0 * inv_n;
+                double var = v1 * inv_n - mu * mu;
+                if (var < 0.0) var = 0.0;
+                const double is = rsqrt(var + g.fin_eps);
+                const float sc = g.xs_gamma[e] * (float)is;
+                const float sh = fmaf(-(float)mu, sc, g.xs_beta[e]);
+                s_xf[e] = sc; s_xf[cin + e] = sh;
+                if (keep) {
+                    g.xs_mean[e] = (float)mu; g.xs_invstd[e] = (float)is; g.xs_scale[e] = sc; g.xs_shift[e] = sh;
+                    if (g.xs_rm) g.xs_rm[e] = (float)(g.fin_momentum * g.xs_rm[e] + (1.0 - g.fin_momentum) * mu);
+                    if (g.xs_rv) g.xs_rv[e] = (float)(g.fin_momentum * g.xs_rv[e] + (1.0 - g.fin_momentum) * var);
+                }
+            }
+        } else {
+            for (int e = tid; e < cin; e += nthreads) { s_xf[e] = g.xf_scale[e]; s_xf[cin + e] = g.xf_shift[e]; }
+        }
+    }
+    // this wave's slab: rows 0..T (T = trash) of slab gi, columns [col0, col0 + 16 NC)
+    float *slab = s_slab + (long)gi * slab_words + lcol0;
+    for (int row = q; row <= T; row += 4)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) slab[(long)row * LDW + 16 * c + r] = 0.f;
+    if constexpr (XF != 0) __syncthreads();
+
+    // pair word of block b for lane (r, q): pair r of the block = input row | row in the tile << 24.  With the weights as
+    // the MFMA's A operand and the gathered rows as its B operand, lane (r, q) ends up with output columns 4q..4q+3 of
+    // pair r: one 16-byte read-modify-write of the slab per column block.  Within one block the pairs have distinct
+    // tile rows, so the plain (non-atomic) update is race-free; padding pairs all hit the trash row, which nobody reads.
+    auto load_idx = [&](int b, int &pv, int &tv) {
+        if (ident) {
+            const int lr = 16 * b + r;
+            pv = lr < rows_here ? (((int)row0 + lr) | (lr << 24)) : (T << 24);
+            tv = 0;
+            return;
+        }
+        pv = blk_p[(long)b * 16 + r];
+        tv = blk_t[b];   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
+    };
+    f32x4 a_cur[KC], a_nxt[KC], w_cur[KC][NC];
+    auto load_a = [&](f32x4 (&a)[KC], int pv, int ch) {
+        const float *src = g.x + (long)(pv & 0xFFFFFF) * g.ldx + ch * (16 * KC) + 4 * q;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) a[j] = *(const f32x4 *)(src + 16 * j);
+    };
+    auto load_w = [&](f32x4 (&w)[KC][NC], int t, int ch) {
+        const int o = g.flip ? (K - 1 - t) : t;
+        const float *src = g.wt + ((long)o * cout + col0 + r) * cin + ch * (16 * KC) + 4 * q;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + (long)(16 * c) * cin + 16 * j);
+    };
+
+    // Steps s = (block, channel chunk).  The gathered rows of step s + 1 are requested before the MFMAs of step s and the
+    // pair words three blocks ahead.  The weight fragments stay in registers while the offset (and chunk) does not
+    // change; when it does they are requested BEFORE the next step's rows, so that waiting for them (s_waitcnt vmcnt(N)
+    // counts in issue order) leaves the younger row loads in flight.
+    if (b0 < b1) {
+        int pv_c, tv_c, pv_n, tv_n, pv_nn, tv_nn;
+        load_idx(b0, pv_c, tv_c);
+        load_idx(b0 + 1 < b1 ? b0 + 1 : b1 - 1, pv_n, tv_n);
+        load_idx(b0 + 2 < b1 ? b0 + 2 : b1 - 1, pv_nn, tv_nn);
+        int t_c = __builtin_amdgcn_readfirstlane(tv_c);
+        load_a(a_cur, pv_c, 0);
+        int w_key = -1;
+        for (int b = b0; b < b1; ++b) {
+            int pv_n3, tv_n3;
+            load_idx(b + 3 < b1 ? b + 3 : b1 - 1, pv_n3, tv_n3);
+            const int t_n = __builtin_amdgcn_readfirstlane(tv_n);
+            // old slab values of this block's rows: requested now, needed after the MFMAs
+            float *dptr = slab + (long)((unsigned)pv_c >> 24) * LDW + 4 * q;
+            f32x4 old[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) old[c] = *(const f32x4 *)(dptr + 16 * c);
+            f32x4 acc[NC], acc2[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int ch = 0; ch < nch; ++ch) {
+                const bool last = ch + 1 == nch;
+                const int key = t_c * nch + ch;
+                if (key != w_key) { load_w(w_cur, t_c, ch); w_key = key; }   // wave-uniform
+                load_a(a_nxt, last ? pv_n : pv_c, last ? 0 : ch + 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs (the scheduler sinks them otherwise)
+                if constexpr (XF != 0) {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const f32x4 sc = *(const f32x4 *)(s_xf + ch * (16 * KC) + 16 * j + 4 * q);
+                        const f32x4 sh = *(const f32x4 *)(s_xf + cin + ch * (16 * KC) + 16 * j + 4 * q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a_cur[j][k] = fmaxf(fmaf(a_cur[j][k], sc[k], sh[k]), 0.f);
+                    }
+                }
+                // D[column 4q+i of the block][pair r] = sum_k W[k][column] x[pair][k]: weights are the A operand.  Two
+                // accumulators alternate so that consecutive MFMAs are independent (40-cycle dependent latency vs 32 issue)
+#pragma unroll
+                for (int j = 0; j < KC; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc2[c]);
+                            else acc[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc[c]);
+                        }
+#pragma unroll
+                for (int j = 0; j < KC; ++j) a_cur[j] = a_nxt[j];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = old[c] + (acc[c] + acc2[c]);
+            pv_c = pv_n; pv_n = pv_nn; pv_nn = pv_n3;
+            t_c = t_n; tv_n = tv_nn; tv_nn = tv_n3;
+        }
+    }
+    __syncthreads();
+
+    // epilogue: wave (cg, gi) finishes columns [col0, col0 + 16 NC) of the rows gi, gi + G, ... in groups of 4 (q)
+    double s0[NC], s1[NC];
+    float esc[NC], esh[NC], emu[NC], eis[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        s0[c] = 0.0; s1[c] = 0.0;
+        esc[c] = esh[c] = emu[c] = eis[c] = 0.f;
+        if (g.epi == 2) {
+            const int col = col0 + 16 * c + r;
+            esc[c] = g.e_scale[col]; esh[c] = g.e_shift[col]; emu[c] = g.e_mean[col]; eis[c] = g.e_invstd[col];
+        }
+    }
+    for (int lr = 4 * gi + q; lr < rows_here; lr += 4 * G) {
+        const long row = row0 + lr;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = col0 + 16 * c + r;
+            float v = 0.f;
+            for (int k = 0; k < G; ++k) v += s_slab[(long)k * slab_words + (long)lr * LDW + (col - colw)];
+            if (g.res) v += g.res[row * cout + col];
+            if (g.epi == 1) {
+                s0[c] += (double)v;
+                s1[c] += (double)v * (double)v;
+            } else if (g.epi == 2) {
+                const float xv = g.e_x[row * cout + col];
+                if (!(fmaf(xv, esc[c], esh[c]) > 0.f)) v = 0.f;
+                const double xh = ((double)xv - (double)emu[c]) * (double)eis[c];
+                s0[c] += (double)v;
+                s1[c] += (double)v * xh;
+            }
+            g.y[row * g.ldy + col] = v;
+        }
+    }
+    if (g.epi == 0) return;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        s0[c] += __shfl_xor(s0[c], 16); s1[c] += __shfl_xor(s1[c], 16);
+        s0[c] += __shfl_xor(s0[c], 32); s1[c] += __shfl_xor(s1[c], 32);
+        if (q == 0) {
+            s_p[(long)(0 * G + gi) * cw + lcol0 + 16 * c + r] = s0[c];
+            s_p[(long)(1 * G + gi) * cw + lcol0 + 16 * c + r] = s1[c];
+        }
+    }
+    __syncthreads();
+    for (int lc = tid; lc < cw; lc += nthreads) {
+        const int col = colw + lc;
+        double v0 = 0.0, v1 = 0.0;
+        for (int k = 0; k < G; ++k) { v0 += s_p[(long)(0 * G + k) * cw + lc]; v1 += s_p[(long)(1 * G + k) * cw + lc]; }
+        if (g.part_slots > 0) {   // accumulate: hardware fp64 add at the memory side, no return value
+            const long slot = tile % (unsigned)g.part_slots;
+            unsafeAtomicAdd(&g.part[(slot * 2 + 0) * cout + col], v0);
+            unsafeAtomicAdd(&g.part[(slot * 2 + 1) * cout + col], v1);
+        } else {
+            g.part[((long)tile * 2 + 0) * cout + col] = v0;
+            g.part[((long)tile * 2 + 1) * cout + col] = v1;
+        }
+    }
+}
+
+int g_pairs_waves = 4096;    // a launch is split G ways until it has about this many waves (urn_set_option "pairs_waves")
+int g_pairs_nc = 0;          // force the column blocks per wave (urn_set_option "pairs_nc"), 0 = automatic
+int g_pairs_split = 0;
+int g_pairs_wgs = 512;       // a workgroup takes several column groups only while the launch keeps this many workgroups ("pairs_wgs")
+int g_pairs_cbg = 0;          // most column groups per workgroup (urn_set_option "pairs_cbg"), 0 = as many as fit       // force G (urn_set_option "pairs_split"), 0 = automatic
+
+template <int KC, int NC>
+static void launch_pairs2(const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+{
+    const bool xf = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
+    if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0>), grid, block, lds, st, a);
+}
+
+// returns the number of partial rows (tiles), 0 when the shape has no instantiation
+int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
+{
+    const int T = a.p_tile;
+    if ((T != 32 && T != 64 && T != 128) || a.cin % 16 || a.cout % 16 || a.K > 27) return 0;
+    const int ks = a.cin / 16, nblk = a.cout / 16;
+    int kc = 1;
+    for (int d : {8, 6, 5, 4, 3, 2})
+        if (ks % d == 0) { kc = d; break; }
+    const long ntiles = (n_out + T - 1) / T;
+    // two column blocks per wave halve the gathers (every wave of a tile gathers the same rows) when the launch still has
+    // enough waves; the weight fragments of an offset must stay in registers (KC * NC * 4 <= 48)
+    int nc = 1;
+    if (nblk % 2 == 0 && kc <= 4 && ntiles * (nblk / 2) >= 2 * g_pairs_wgs) nc = 2;
+    if (g_pairs_nc == 1 || (g_pairs_nc == 2 && nblk % 2 == 0 && kc <= 6)) nc = g_pairs_nc;
+    const int cbg_all = nblk / nc;
+    const int maxw = kc * (nc + 2) * 4 <= 64 ? 16 : 8;   // waves per workgroup (register budget, see __launch_bounds__)
+    // Workgroups first: the deep levels have few tiles (103 of 64 rows at level 3 of cfg3), and one workgroup per tile left
+    // most of the 256 CUs idle (measured 56 -> 15 us at level 4, 80 -> 80, with one column group per workgroup): give a
+    // workgroup fewer column groups (its rows are then gathered by several workgroups -- L2 hits) until the launch has
+    // g_pairs_wgs workgroups; then split the block lists G ways.
+    int cbg = 1;
+    for (int d = cbg_all < maxw ? cbg_all : maxw; d >= 1; --d)
+        if (cbg_all % d == 0 && (d == 1 || ntiles * (cbg_all / d) >= g_pairs_wgs)) { cbg = d; break; }
+    if (g_pairs_cbg > 0 && cbg_all % g_pairs_cbg == 0 && g_pairs_cbg <= maxw) cbg = g_pairs_cbg;
+    const int gy = cbg_all / cbg, cw = 16 * nc * cbg;
+    auto lds_bytes = [&](int G) {
+        size_t w = (size_t)2 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
+        return w * 4 + (size_t)2 * G * cw * 8;
+    };
+    int G = 1;
+    while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < g_pairs_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= 65536) ++G;
+    if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= 65536) G = g_pairs_split;
+    if (lds_bytes(G) > 65536) return 0;
+    a.p_split = G; a.p_cw = cw;
+    const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
+    const size_t lds = lds_bytes(G);
+#define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs2<KCv, NCv>(a, grid, block, lds, st); return (int)ntiles; }
+    URN_PL(1, 1) URN_PL(2, 1) URN_PL(3, 1) URN_PL(4, 1) URN_PL(5, 1) URN_PL(6, 1) URN_PL(8, 1)
+    URN_PL(1, 2) URN_PL(2, 2) URN_PL(3, 2) URN_PL(4, 2) URN_PL(5, 2) URN_PL(6, 2)
+#undef URN_PL
+    return 0;
+}

@@ -82,6 +82,24 @@ struct Geo {
     std::vector<int64_t> n;
     std::vector<const int32_t *> nbr, chd, up;
     const int32_t *row2site = nullptr;
+    // compacted rule lists of the tables (urn_pairs_build), handed over by urn_net_set_pairs; tile 0 = none
+    std::vector<const int32_t *> p_nbr, p_chd, p_up;
+    std::vector<int> t_nbr, t_chd, t_up;   // tile size per level (0 = no list)
+    // list and tile of a table of this geometry; the centre row of a submanifold table is the identity (list NULL)
+    void pairs_of(const int32_t *tbl, const int32_t *&list, int &tile) const
+    {
+        list = nullptr; tile = 0;
+        for (int l = 0; l < L; ++l) {
+            if (l < (int)p_nbr.size() && p_nbr[l] && t_nbr[l]) {
+                if (tbl == nbr[l]) { list = p_nbr[l]; tile = t_nbr[l]; return; }
+                if (tbl == nbr[l] + 13 * ld) { tile = t_nbr[l]; return; }
+            }
+            if (l + 1 < L) {
+                if (l < (int)p_chd.size() && p_chd[l] && t_chd[l] && tbl == chd[l]) { list = p_chd[l]; tile = t_chd[l]; return; }
+                if (l < (int)p_up.size() && p_up[l] && t_up[l] && tbl == up[l]) { list = p_up[l]; tile = t_up[l]; return; }
+            }
+        }
+    }
 };
 
 struct ConvP { int64_t w; int K, cin, cout; const float *x = nullptr; };           // saved input
@@ -128,6 +146,7 @@ struct urn_net {
     size_t ev_next = 0;
     bool side_used = false;
     bool side_probed = false;
+    bool pairs_armed = false;            // urn_net_set_pairs was called for the coming forward
     // keep the fastest of g_net_side_probe candidate side streams for this executor's main stream (see probe_pair)
     void pick_side()
     {
@@ -199,11 +218,22 @@ struct urn_net {
     void check(int r) { if (r != URN_OK && rc == URN_OK) rc = r; }
     bool live() const { return !arena.dry && rc == URN_OK && !arena.overflow; }
 
+    // a gather convolution without fusions, on the compacted rule list of its table when the geometry carries one
+    int gconv_plain(const float *x, const float *wt, const int32_t *tbl, int K, int flip, int64_t n_out, int cin, int cout,
+                    const float *res, float *y)
+    {
+        urn_gconv_args a;
+        memset(&a, 0, sizeof(a));
+        a.x = x; a.wt = wt; a.tbl = tbl; a.ld = geo.ld; a.K = K; a.flip = flip; a.n_out = n_out; a.cin = cin; a.cout = cout;
+        a.res = res; a.y = y;
+        geo.pairs_of(tbl, a.pairs, a.pairs_tile);
+        return urn_gconv_fwd_ex(&a, nullptr, st);
+    }
     float *conv_fwd(ConvP &c, const float *x, const int32_t *tbl, int64_t n_out, const float *res)
     {
         c.x = x;
         float *y = arena.f32(n_out * c.cout);
-        if (live()) check(urn_gconv_fwd(x, wt_all + c.w, tbl, geo.ld, c.K, 0, n_out, c.cin, c.cout, res, y, st));
+        if (live()) check(gconv_plain(x, wt_all + c.w, tbl, c.K, 0, n_out, c.cin, c.cout, res, y));
         return y;
     }
     // returns dx (n_in, cin); accumulates dW into grads
@@ -212,7 +242,7 @@ struct urn_net {
     {
         float *dx = need_dx ? arena.f32(n_in * c.cin) : nullptr;
         if (live()) {
-            if (need_dx) check(urn_gconv_fwd(dy, params + c.w, tbl_b, geo.ld, c.K, flip_b, n_in, c.cout, c.cin, nullptr, dx, st));
+            if (need_dx) check(gconv_plain(dy, params + c.w, tbl_b, c.K, flip_b, n_in, c.cout, c.cin, nullptr, dx));
             hipStream_t ws = st;
             if (side && !events.empty()) {
                 // fork: dy (and everything before it) is complete on the main stream at this point
@@ -400,6 +430,7 @@ struct urn_net {
         a.x = in.x; a.wt = wt_all + c.w; a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
         a.cin = c.cin; a.cout = c.cout; a.res = res; a.y = y.x;
         a.ldy = dst ? ld_dst : 0;
+        geo.pairs_of(tbl, a.pairs, a.pairs_tile);
         a.fin_eps = eps; a.fin_momentum = momentum;
         if (xs) {
             a.xs_slots = SUM_SLOTS; a.xs_n = in.n;
@@ -487,6 +518,7 @@ struct urn_net {
             memset(&a, 0, sizeof(a));
             a.x = dy; a.wt = params + c.w; a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
             a.cin = c.cout; a.cout = c.cin; a.y = g; a.ldx = ld_dy;
+            geo.pairs_of(tbl_b, a.pairs, a.pairs_tile);
             a.epilogue = 2; a.part = part;
             a.e_x = b.x; a.e_scale = b.scale; a.e_shift = b.shift; a.e_mean = b.mean; a.e_invstd = b.invstd;
             int n_part = 0;
@@ -769,11 +801,32 @@ extern "C" int urn_net_tensor(const urn_net *n, int i, int64_t *off, int64_t *nu
     return URN_OK;
 }
 
+extern "C" int urn_net_set_pairs(urn_net *net, int num_levels, const void *const *nbr_pairs, const void *const *chd_pairs,
+                                 const void *const *up_pairs, const int *tile_nbr, const int *tile_chd, const int *tile_up)
+{
+    URN_CHECK_ARG(net && num_levels == net->L, "level count does not match the network");
+    URN_CHECK_ARG((!nbr_pairs || tile_nbr) && (!chd_pairs || tile_chd) && (!up_pairs || tile_up), "lists without tile sizes");
+    Geo &g = net->geo;
+    g.p_nbr.assign(num_levels, nullptr); g.p_chd.assign(num_levels, nullptr); g.p_up.assign(num_levels, nullptr);
+    g.t_nbr.assign(num_levels, 0); g.t_chd.assign(num_levels, 0); g.t_up.assign(num_levels, 0);
+    for (int l = 0; l < num_levels; ++l) {
+        if (nbr_pairs) { g.p_nbr[l] = (const int32_t *)nbr_pairs[l]; g.t_nbr[l] = tile_nbr[l]; }
+        if (l + 1 < num_levels) {
+            if (chd_pairs) { g.p_chd[l] = (const int32_t *)chd_pairs[l]; g.t_chd[l] = tile_chd[l]; }
+            if (up_pairs) { g.p_up[l] = (const int32_t *)up_pairs[l]; g.t_up[l] = tile_up[l]; }
+        }
+    }
+    net->pairs_armed = true;
+    return URN_OK;
+}
+
 static int set_geo(urn_net *net, int num_levels, int64_t ld, const int64_t *n, const void *const *nbr, const void *const *chd,
                    const void *const *up, const int32_t *row2site, int64_t n_rows)
 {
     URN_CHECK_ARG(num_levels == net->L && n, "geometry level count does not match the network");
     Geo &g = net->geo;
+    if (!net->pairs_armed) { g.p_nbr.clear(); g.p_chd.clear(); g.p_up.clear(); }   // lists belong to ONE geometry: the next forward only
+    net->pairs_armed = false;
     g.L = num_levels; g.ld = ld; g.n_rows = n_rows; g.row2site = row2site;
     g.n.assign(n, n + num_levels);
     g.nbr.assign(num_levels, nullptr); g.chd.assign(num_levels, nullptr); g.up.assign(num_levels, nullptr);

@@ -35,7 +35,7 @@ class GConvArgs(ctypes.Structure):
                 ('xs_gamma', ctypes.c_void_p), ('xs_beta', ctypes.c_void_p), ('xs_mean', ctypes.c_void_p),
                 ('xs_invstd', ctypes.c_void_p), ('xs_scale', ctypes.c_void_p), ('xs_shift', ctypes.c_void_p),
                 ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p), ('precision', ctypes.c_int),
-                ('ldx', ctypes.c_int64), ('ldy', ctypes.c_int64)]
+                ('ldx', ctypes.c_int64), ('ldy', ctypes.c_int64), ('pairs', ctypes.c_void_p), ('pairs_tile', ctypes.c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/uresnet_hip.h
@@ -63,6 +63,8 @@ SIGNATURES = {
                                         c_void_p]),
     'urn_down_tables': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
     'urn_fill_i32': (c_int, [c_void_p, c_i64, ctypes.c_int32, c_void_p]),
+    'urn_pairs_bytes': (c_i64, [c_i64, c_int, c_int]),
+    'urn_pairs_build': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_gconv_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_int, c_int, c_void_p,
                               c_void_p, c_void_p]),
     'urn_gconv_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p,
@@ -108,6 +110,9 @@ SIGNATURES = {
     'urn_net_num_tensors': (c_int, [c_void_p]),
     'urn_net_tensor': (c_int, [c_void_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     'urn_net_workspace_bytes': (c_i64, [c_void_p, c_int, ctypes.POINTER(c_i64), c_i64, c_int]),
+    'urn_net_set_pairs': (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                  ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                  ctypes.POINTER(c_int)]),
     'urn_net_forward': (c_int, [c_void_p, c_int, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_void_p),
                                 ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_i64, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p]),

@@ -133,7 +133,8 @@ class SubmanifoldConvolution(nn.Module):
 
     def forward(self, x, res=None):
         g, l = x.geometry, x.level
-        y = so.GConvFunction.apply(x.features, self.weight, res, g.nbr[l], g.nbr[l], 1, g.ld, g.n[l], g.n[l])
+        y = so.GConvFunction.apply(x.features, self.weight, res, g.nbr[l], g.nbr[l], 1, g.ld, g.n[l], g.n[l],
+                                   g.pairs['nbr'][l], g.pairs['nbr'][l])
         return x.with_features(y)
 
 
@@ -152,7 +153,8 @@ class Convolution(nn.Module):
         g, l = x.geometry, x.level
         if l + 1 >= g.num_levels:
             raise RuntimeError('geometry was built with %d levels; InputLayer.num_levels too small' % g.num_levels)
-        y = so.GConvFunction.apply(x.features, self.weight, None, g.chd[l], g.up[l], 0, g.ld, g.n[l + 1], g.n[l])
+        y = so.GConvFunction.apply(x.features, self.weight, None, g.chd[l], g.up[l], 0, g.ld, g.n[l + 1], g.n[l],
+                                   g.pairs['chd'][l], g.pairs['up'][l])
         return x.with_features(y, l + 1)
 
 
@@ -169,7 +171,8 @@ class Deconvolution(nn.Module):
 
     def forward(self, x):
         g, l = x.geometry, x.level - 1
-        y = so.GConvFunction.apply(x.features, self.weight, None, g.up[l], g.chd[l], 0, g.ld, g.n[l], g.n[l + 1])
+        y = so.GConvFunction.apply(x.features, self.weight, None, g.up[l], g.chd[l], 0, g.ld, g.n[l], g.n[l + 1],
+                                   g.pairs['up'][l], g.pairs['chd'][l])
         return x.with_features(y, l)
 
 
@@ -187,7 +190,8 @@ class NetworkInNetwork(nn.Module):
     def forward(self, x):
         g, l = x.geometry, x.level
         ident = g.nbr[l][13:14]       # centre offset of the submanifold table = identity map
-        y = so.GConvFunction.apply(x.features, self.weight.unsqueeze(0), None, ident, ident, 0, g.ld, g.n[l], g.n[l])
+        y = so.GConvFunction.apply(x.features, self.weight.unsqueeze(0), None, ident, ident, 0, g.ld, g.n[l], g.n[l],
+                                   so.IDENT_PAIRS, so.IDENT_PAIRS)
         return x.with_features(y)
 
 

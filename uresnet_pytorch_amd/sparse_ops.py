@@ -2,6 +2,7 @@
 call the HIP kernels through the C ABI.  PyTorch only owns memory and the stream.
 """
 import ctypes
+import os
 
 import torch
 
@@ -109,8 +110,47 @@ class SparseGeometry:
         self._scratch = scratch
         self._rules = None
         self.n = None
+        self._build_pairs(L, st)
         if not defer_sync:
             self.sync()
+
+    # Tile sizes of the compacted rule lists, by level: 64 output rows; 128 for the fine<-parent table (one rule per row
+    # spread over 8 offsets: a 64-row tile would half-fill its blocks).  32-row tiles for the small deep levels were
+    # measured slower (cfg3 step 3.25 vs 3.24 ms; level 3, 64 -> 64 alone 33 vs 26 us).  URN_PAIRS_TILES="nbr;chd;up"
+    # (comma-separated per level) overrides.
+    PAIRS_TILES = {'nbr': [64], 'chd': [64], 'up': [128]}
+
+    @classmethod
+    def pairs_tile(cls, kind, level):
+        env = os.environ.get('URN_PAIRS_TILES')
+        tiles = cls.PAIRS_TILES
+        if env:
+            tiles = dict(zip(('nbr', 'chd', 'up'), [[int(v) for v in part.split(',')] for part in env.split(';')]))
+        lst = tiles[kind]
+        return lst[min(level, len(lst) - 1)]
+
+    def _build_pairs(self, L, st):
+        """Compacted rule lists of every gather table (one launch): what the MFMA kernels walk.  Row counts stay on the
+        device.  self.pairs[kind][level] = (int32 tensor, tile) for kind in nbr / chd / up."""
+        nl, cap, dev = self.num_levels, self.cap, self.device
+        cptr = self.counts.data_ptr()
+        jobs = [('nbr', l, self.nbr[l], 27, cptr + 4 * l) for l in range(nl)]
+        jobs += [('chd', l, self.chd[l], 8, cptr + 4 * (l + 1)) for l in range(nl - 1)]
+        jobs += [('up', l, self.up[l], 8, cptr + 4 * l) for l in range(nl - 1)]
+        self.pairs = {'nbr': [None] * nl, 'chd': [None] * max(nl - 1, 0), 'up': [None] * max(nl - 1, 0)}
+        tiles = [self.pairs_tile(kind, l) for kind, l, _, _, _ in jobs]
+        sizes = [L.urn_pairs_bytes(cap, K, T) // 4 for (_, _, _, K, _), T in zip(jobs, tiles)]
+        self._pairs_all = torch.empty(sum(sizes), dtype=torch.int32, device=dev)
+        outs, off = [], 0
+        for (kind, l, _, _, _), sz, T in zip(jobs, sizes, tiles):
+            t = self._pairs_all[off:off + sz]
+            self.pairs[kind][l] = (t, T)
+            outs.append(t.data_ptr()); off += sz
+        n = len(jobs)
+        PA, I64A, IA = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+        _l.check(L.urn_pairs_build(n, PA(*[j[2].data_ptr() for j in jobs]), I64A(*([cap] * n)), IA(*[j[3] for j in jobs]),
+                                   PA(*[j[4] for j in jobs]), I64A(*([cap] * n)), IA(*tiles),
+                                   PA(*outs), st), 'pairs_build')
 
     def sync(self):
         """the one host synchronisation of the integer phase: per-level site counts"""
@@ -150,11 +190,23 @@ def input_features(geo, feats):
     return out
 
 
-def _gconv(x, wt, tbl, ld, K, flip, n_out, cin, cout, res=None):
+IDENT_PAIRS = (None, 64)     # the identity table of a 1x1 convolution needs no list
+
+
+def _gconv(x, wt, tbl, ld, K, flip, n_out, cin, cout, res=None, pairs=None):
+    """pairs = (list tensor or None, tile): run on the compacted rule list of `tbl` (see SparseGeometry.pairs)"""
     L = _l.load()
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-    _l.check(L.urn_gconv_fwd(_l.ptr(x), _l.ptr(wt), tbl.data_ptr(), ld, K, flip, n_out, cin, cout, _l.ptr(res),
-                             y.data_ptr(), _l.stream()), 'gconv_fwd')
+    if pairs is None:
+        _l.check(L.urn_gconv_fwd(_l.ptr(x), _l.ptr(wt), tbl.data_ptr(), ld, K, flip, n_out, cin, cout, _l.ptr(res),
+                                 y.data_ptr(), _l.stream()), 'gconv_fwd')
+        return y
+    a = _l.GConvArgs()
+    a.x = _l.ptr(x); a.wt = _l.ptr(wt); a.tbl = tbl.data_ptr(); a.ld = ld; a.K = K; a.flip = flip; a.n_out = n_out
+    a.cin = cin; a.cout = cout; a.res = _l.ptr(res); a.y = y.data_ptr()
+    a.pairs = None if pairs[0] is None else pairs[0].data_ptr()
+    a.pairs_tile = pairs[1]
+    _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
     return y
 
 
@@ -172,15 +224,16 @@ class GConvFunction(torch.autograd.Function):
     (submanifold: the inverse of nbr[o] is nbr[26-o])."""
 
     @staticmethod
-    def forward(ctx, x, weight, res, tbl_f, tbl_b, flip_b, ld, n_out, n_in):
+    def forward(ctx, x, weight, res, tbl_f, tbl_b, flip_b, ld, n_out, n_in, pairs_f=None, pairs_b=None):
         _l.require_gpu(x)
         x = x.contiguous(); weight = weight.contiguous()
         K, cin, cout = weight.shape
         assert x.shape == (n_in, cin), (x.shape, n_in, cin)
         wt = _transpose_w(weight)
-        y = _gconv(x, wt, tbl_f, ld, K, 0, n_out, cin, cout, None if res is None else res.contiguous())
+        y = _gconv(x, wt, tbl_f, ld, K, 0, n_out, cin, cout, None if res is None else res.contiguous(), pairs_f)
         ctx.save_for_backward(x, weight)
         ctx.meta = (tbl_f, tbl_b, flip_b, ld, n_out, n_in, res is not None)
+        ctx.pairs_b = pairs_b
         return y
 
     @staticmethod
@@ -194,13 +247,13 @@ class GConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dx[i] = sum_o dy[inv[o][i]] @ W[o]^T : same kernel, W itself is the
             # "(K, cout_eff=cin, cin_eff=cout)" transposed operand
-            dx = _gconv(dy, weight, tbl_b, ld, K, flip_b, n_in, cout, cin)
+            dx = _gconv(dy, weight, tbl_b, ld, K, flip_b, n_in, cout, cin, None, ctx.pairs_b)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight)
             _l.check(L.urn_gconv_bwd_dw(_l.ptr(x), _l.ptr(dy), tbl_f.data_ptr(), ld, K, n_out, cin, cout,
                                         dw.data_ptr(), _l.stream()), 'gconv_bwd_dw')
         dres = dy if (has_res and ctx.needs_input_grad[2]) else None
-        return dx, dw, dres, None, None, None, None, None, None
+        return dx, dw, dres, None, None, None, None, None, None, None, None
 
 
 class BNReLUFunction(torch.autograd.Function):

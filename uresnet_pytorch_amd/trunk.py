@@ -221,6 +221,12 @@ class TrunkExecutor:
             nbr=(ctypes.c_void_p * Lv)(*[t.data_ptr() for t in geo.nbr]),
             chd=(ctypes.c_void_p * Lv)(*([t.data_ptr() for t in geo.chd] + [None])),
             up=(ctypes.c_void_p * Lv)(*([t.data_ptr() for t in geo.up] + [None])),
+            p_nbr=(ctypes.c_void_p * Lv)(*[t[0].data_ptr() for t in geo.pairs['nbr']]),
+            p_chd=(ctypes.c_void_p * Lv)(*([t[0].data_ptr() for t in geo.pairs['chd']] + [None])),
+            p_up=(ctypes.c_void_p * Lv)(*([t[0].data_ptr() for t in geo.pairs['up']] + [None])),
+            t_nbr=(ctypes.c_int * Lv)(*[t[1] for t in geo.pairs['nbr']]),
+            t_chd=(ctypes.c_int * Lv)(*([t[1] for t in geo.pairs['chd']] + [0])),
+            t_up=(ctypes.c_int * Lv)(*([t[1] for t in geo.pairs['up']] + [0])),
             out=torch.empty((geo.n_rows, self.cfg[0]), dtype=torch.float32, device=geo.device))
 
     def forward(self, geo, feats, training):
@@ -248,6 +254,8 @@ class _TrunkFunction(torch.autograd.Function):
         ws, ws_bytes = ex.workspace(slot, geo, need_bwd)
         n = (ctypes.c_int64 * Lv)(*geo.n)
         feats = feats.contiguous()
+        _l.check(L.urn_net_set_pairs(slot.handle, Lv, prep['p_nbr'], prep['p_chd'], prep['p_up'], prep['t_nbr'], prep['t_chd'],
+                                     prep['t_up']), 'net_set_pairs')
         _l.check(L.urn_net_forward(slot.handle, Lv, geo.ld, n, nbr, chd, up, geo.row2site.data_ptr(), geo.n_rows,
                                    ex.flat.data_ptr(), ex.running.data_ptr(), feats.data_ptr(), ws.data_ptr(),
                                    ws_bytes, out.data_ptr(), int(training), _l.stream()), 'net_forward')
