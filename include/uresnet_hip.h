@@ -110,10 +110,11 @@ int urn_fill_i32(int32_t *p, int64_t n, int32_t v, void *stream);
 
 /* Compacted rule lists ("pair lists") of gather tables, the form the MFMA kernels consume (the rulebook of
  * scn.SubmanifoldConvolution / Convolution / Deconvolution, reference uresnet_sparse.py:21-22, grouped per tile of
- * `tile` (32, 64 or 128) output rows): per tile [0] = number of blocks, then the table row t of every block, then 16 words
- * per block, word = input row | (row inside the tile << 24); blocks are ordered by t, a table row's last block is padded
- * with words (tile << 24) (gather row 0, discard).  urn_pairs_bytes = size of one list; urn_pairs_build compacts n_tables
- * tables (host arrays of n_tables entries; n_dev[i] = device int32 row count or NULL = n_cap[i]) in one launch.
+ * `tile` (32, 64 or 128) output rows).  One tile = int32 words [0] number of blocks | bytes 4..31: first block of every
+ * table row t | the table row t of every block (K*tile/16 words, padded to a multiple of 4) | 16 words per block, word =
+ * input row | (row inside the tile << 24); blocks are ordered by t, a table row's last block is padded with words
+ * (tile << 24) (gather row 0, discard).  urn_pairs_bytes = size of one list; urn_pairs_build compacts n_tables tables (host
+ * arrays of n_tables entries; n_dev[i] = device int32 row count or NULL = n_cap[i]) in one launch.
  * Deterministic: the list depends on the table only. */
 int64_t urn_pairs_bytes(int64_t n_cap, int K, int tile);
 int urn_pairs_build(int n_tables, const int32_t *const *tbl, const int64_t *ld, const int *K,
@@ -134,6 +135,15 @@ int urn_gconv_fwd(const float *x, const float *wt, const int32_t *tbl, int64_t l
  * dw is (K, cin, cout) and is ACCUMULATED into (fp32 atomics; caller zeroes). */
 int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *tbl, int64_t ld, int K,
                      int64_t n_out, int cin, int cout, float *dw, void *stream);
+
+/* Weight gradient on the compacted rule list of the table (NULL list = identity table, K == 1), two stages without
+ * atomics: per (share of the tiles, table row) partial sums in `scratch` (urn_gconv_dw_pairs_scratch_bytes), then
+ * dw += the partials in a fixed order -- bitwise reproducible.  x rows are used as relu(x*scale+shift) when xf_scale is
+ * given; ldx / ld_dy = row strides of x / dy in floats (0 = cin / cout).  cin, cout multiples of 16. */
+int64_t urn_gconv_dw_pairs_scratch_bytes(int64_t n_out, int tile, int K, int cin, int cout);
+int urn_gconv_bwd_dw_pairs(const float *x, int64_t ldx, const float *xf_scale, const float *xf_shift, const float *dy,
+                           int64_t ld_dy, const int32_t *pairs, int tile, int K, int64_t n_out, int cin, int cout,
+                           float *dw, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* (K, a, b) -> (K, b, a) */
 int urn_transpose_w(const float *w, int K, int a, int b, float *wt, void *stream);
@@ -317,6 +327,14 @@ int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const int64_t *n, 
                     const float *params, float *running, const float *site_feats, void *ws, int64_t ws_bytes,
                     float *out_rows, int training, void *stream);
 int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stream);
+
+/* Test hook: the folded BatchNorm+ReLU of the last TRAINING forward on the fused path.  BatchNorm i (0 <= i <
+ * urn_net_num_bn, executor order; w_off = offset of its weight in the flat parameter buffer) consumed x (rows, c) as
+ * relu(x * scale + shift); urn_net_bn_export copies x, scale and shift into caller buffers (device to device, on stream).
+ * Parity tests pin the oracle's ReLU masks with them (the normalised tensor itself is never written). */
+int urn_net_num_bn(urn_net *net);
+int urn_net_bn_info(urn_net *net, int i, int64_t *w_off, int64_t *rows, int *c);
+int urn_net_bn_export(urn_net *net, int i, float *x, float *scale, float *shift, void *stream);
 
 /* ----------------------------------------------------------------------- measurement
  * Optional per-kernel timing (HIP events on the launch stream), off by default.

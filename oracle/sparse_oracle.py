@@ -262,12 +262,23 @@ class SparseUResNetOracle:
 
     def _bn(self, prefix, x):
         g, b = self.P[prefix + '.weight'], self.P[prefix + '.bias']
-        y, mean, invstd = bn_relu_fwd(x, g, b, True)
+        masks = getattr(self, 'masks', None)
+        if masks is not None and prefix in masks:
+            # ReLU mask pinned from outside (the GPU's): y = mask * (affine-normalised x).  A pre-activation within fp32
+            # rounding of zero flips between any two evaluation orders; with the mask pinned, forward and backward of
+            # both sides take the same branch and what is left to compare is arithmetic.
+            y, mean, invstd = bn_relu_fwd(x, g, b, False)
+            y = np.where(masks[prefix], y, np.float32(0)).astype(np.float32)
+            # (the backward reads the mask from y > 0: make kept-but-nonpositive entries count as kept)
+            ymask = masks[prefix].astype(np.float32)
+        else:
+            y, mean, invstd = bn_relu_fwd(x, g, b, True)
+            ymask = y
         if getattr(self, 'keep_acts', False):
             self.acts[prefix] = y
 
         def back(dy):
-            dx, dg, db = bn_relu_bwd(x, y, dy, g, mean, invstd, True)
+            dx, dg, db = bn_relu_bwd(x, ymask, dy, g, mean, invstd, True)
             self.G[prefix + '.weight'] = self.G.get(prefix + '.weight', 0) + dg
             self.G[prefix + '.bias'] = self.G.get(prefix + '.bias', 0) + db
             return dx

@@ -43,7 +43,7 @@ def cloud(seed, S, n, nbatch):
 
 
 def pairs_ref(tbl, n, T):
-    """numpy restatement of the list layout: per tile [nblk | 15 unused | t of every block | 16 words per block]"""
+    """numpy restatement of the list layout: per tile [nblk | 28 bytes: first block of every table row | t of every block | 16 words per block]"""
     K = tbl.shape[0]
     maxb = K * (T // 16)
     out = []
@@ -64,13 +64,19 @@ def pairs_ref(tbl, n, T):
 
 def check_pairs(lst, tile, tbl, n, K):
     maxb = K * (tile // 16)
-    words = 16 + maxb + maxb * 16
-    got = lst.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    tpad = (maxb + 3) // 4 * 4
+    words = 16 + tpad + maxb * 16
+    raw = lst.cpu().numpy()
+    got = raw.astype(np.int64) & 0xFFFFFFFF
     for i, (nb, ts, w, _) in enumerate(pairs_ref(tbl, n, tile)):
         base = i * words
         assert got[base] == nb, (i, got[base], nb)
         assert np.array_equal(got[base + 16:base + 16 + nb], ts)
-        assert np.array_equal(got[base + 16 + maxb:base + 16 + maxb + 16 * nb], w & 0xFFFFFFFF)
+        assert np.array_equal(got[base + 16 + tpad:base + 16 + tpad + 16 * nb], w & 0xFFFFFFFF)
+        # header bytes 4 .. 4 + K: the first block of every table row
+        start = raw[base + 1:base + 8].view(np.uint8)[:K]
+        first = np.searchsorted(ts, np.arange(K), side='left')
+        assert np.array_equal(start, first.astype(np.uint8)), (i, start, first)
 
 
 @pytest.mark.parametrize('seed,S,n,nb,L', [(1, 24, 400, 2, 3), (2, 64, 3000, 3, 4), (3, 16, 50, 1, 2), (4, 8, 1, 1, 2)])
@@ -128,9 +134,16 @@ def test_pairs_subm_conv(dev, cin, cout):
     ref = orc.Geometry(c, f, S, 1)
     n = ref.n[0]
     p = geo.pairs['nbr'][0]
-    a = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
-    b = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
+    so.set_deterministic_dw(True)      # weight gradient on the two-stage pair-list kernel
+    try:
+        a = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
+        b = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
+    finally:
+        so.set_deterministic_dw(False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), 'forward / input gradient not bitwise reproducible'
+    assert torch.equal(a[2], b[2]), 'weight gradient not bitwise reproducible (two-stage sum, no atomics)'
+    # ... and the default weight-gradient kernel (dense table, fp32 atomics) against the oracle as well
+    run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
 
 
 @pytest.mark.parametrize('cin,cout', [(16, 32), (64, 80), (48, 32), (32, 48)])
@@ -171,6 +184,7 @@ def test_conv_ops_on_cfg3_geometry(dev, cfg3, level):
     SubM3 P->P and 2P->P, NiN 2P->P, Convolution P->P', Deconvolution P'->P -- forward, dX, dW <= 1e-5 vs the oracle"""
     from uresnet_pytorch_amd import sparse_ops as so
     geo, ref = cfg3
+    so.set_deterministic_dw(level % 2 == 0)   # both weight-gradient kernels see the real geometry
     l, P = level, 16 * (level + 1)
     n = ref.n[l]
     p = geo.pairs['nbr'][l]
@@ -185,6 +199,7 @@ def test_conv_ops_on_cfg3_geometry(dev, cfg3, level):
                  geo.ld, False, 6, tbl_b=geo.up[l])
         run_conv(dev, geo.up[l], ref.up[l], ref.up_inv[l], n, nc, P2, P, geo.pairs['up'][l], geo.pairs['chd'][l], 0,
                  geo.ld, False, 7, tbl_b=geo.chd[l])
+    so.set_deterministic_dw(False)
 
 
 def test_pairs_fused_epilogues_match_tile_kernel(dev):

@@ -20,13 +20,12 @@ def run(n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-policies = [('tile only', 0, 0, 0, 6), ('all subm+strided', 999, 999, 0, 7), ('cin<=64,cout<=48', 64, 48, 0, 7), ('cin<=48', 48, 999, 0, 7)]
+policies = [('tile only', 0, 0, 0, 6), ('all subm+strided', 999, 999, 0, 7), ('cin<=80', 80, 999, 0, 7), ('all, dwp smax 8', 999, 999, 0, 7, 8), ('all, dwp waves 4096', 999, 999, 0, 7, 16, 4096)]
 res = {p[0]: [] for p in policies}
 for rnd in range(3):
     for name, mi, mo, nin, k, *rest in policies:
-        L.urn_set_option(b'pairs_wgs', rest[0] if rest else 512)
+        L.urn_set_option(b'dwp_smax', rest[0] if rest else 16); L.urn_set_option(b'dwp_waves', rest[1] if len(rest) > 1 else 2048)
         L.urn_set_option(b'gconv_kernel', k); L.urn_set_option(b'pairs_max_cin', mi); L.urn_set_option(b'pairs_max_cout', mo); L.urn_set_option(b'pairs_nin', nin)
         res[name].append(run())
-print('URN_PAIRS_TILES', os.environ.get('URN_PAIRS_TILES'))
 for name, *_ in policies:
     print('%-20s ms/step min %.3f  all %s' % (name, min(res[name]), ' '.join('%.3f' % v for v in res[name])), flush=True)

@@ -253,12 +253,13 @@ struct Pick { int mb, nb; };
 // tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
 // before the column tile is widened
 int g_opt_precision = 0;   // default MFMA operand precision of the gather convolutions: 0 fp32, 1 bf16, 2 fp16
+extern int g_dw_pairs;
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
 static int g_opt_fin_in_kernel = 0;
 static int g_opt_pipe = 0;
 static int g_opt_kernel = 7;   // 7 = compacted rule lists when the call carries them (urn_gconv_pairs.hip), else the 2-D tile; 6 = 2-D workgroup tile (urn_gconv_tile.hip); 3 = register gather (fallback for shapes without a tile instantiation)
-extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs;
+extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs, g_dwp_waves, g_dwp_smax, g_dwp_dbg, g_dwp_cap;
 // which calls that carry a pair list run on the pair-list kernel (measured per shape on the cfg3 geometry, tools/bench_pairs.py:
 // it wins for the strided pair and the narrow levels; the wide, small levels are faster on the LDS-staged 2-D tile kernel):
 // K == 8, or K == 27 with cin <= g_pairs_max_cin and cout <= g_pairs_max_cout; K == 1 only when g_pairs_nin is set
@@ -278,6 +279,11 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "pairs_nc")) { g_pairs_nc = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_cbg")) { g_pairs_cbg = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_wgs")) { g_pairs_wgs = (int)value; return URN_OK; }
+    if (!strcmp(key, "dw_pairs")) { g_dw_pairs = value != 0; return URN_OK; }
+    if (!strcmp(key, "dwp_cap")) { g_dwp_cap = value >= 1 && value <= 5 ? (int)value : 2; return URN_OK; }
+    if (!strcmp(key, "dwp_dbg")) { g_dwp_dbg = (int)value; return URN_OK; }
+    if (!strcmp(key, "dwp_waves")) { g_dwp_waves = (int)value; return URN_OK; }
+    if (!strcmp(key, "dwp_smax")) { g_dwp_smax = value > 0 && value <= 256 ? (int)value : 16; return URN_OK; }
     if (!strcmp(key, "pairs_split")) { g_pairs_split = (int)value; return URN_OK; }
     if (!strcmp(key, "gconv_dbg")) { g_opt_dbg = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_rb")) { g_tile_rb = (int)value; return URN_OK; }

@@ -42,7 +42,11 @@ struct GArgs {
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };
 
-#define URN_PAIRS_HDR 16   // int32 words in front of a tile's block list ([0] = number of blocks)
+#define URN_PAIRS_HDR 16   // int32 words in front of a tile's block list ([0] = number of blocks, bytes 4..31 = first block of every table row)
+// layout of one tile of a pair list: header | table row of every block (padded to a multiple of 4 words) | 16 words per block
+static __host__ __device__ inline long urn_pairs_maxb(int K, int T) { return (long)K * (T / 16); }
+static __host__ __device__ inline long urn_pairs_tpad(int K, int T) { return (urn_pairs_maxb(K, T) + 3) & ~3L; }
+static __host__ __device__ inline long urn_pairs_words(int K, int T) { return URN_PAIRS_HDR + urn_pairs_tpad(K, T) + urn_pairs_maxb(K, T) * 16; }
 // compacted rule lists (urn_gconv_pairs.hip): returns the number of partial rows (tiles), 0 = no instantiation
 int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st);
 // 2-D workgroup tile (urn_gconv_tile.hip): returns the number of partial rows, 0 = no instantiation

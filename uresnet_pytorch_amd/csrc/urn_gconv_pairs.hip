@@ -24,12 +24,6 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-static __host__ __device__ inline long pairs_tile_words(int K, int T)
-{
-    const long maxb = (long)K * (T / 16);
-    return URN_PAIRS_HDR + maxb + maxb * 16;
-}
-
 // ------------------------------------------------------------------------------------------------ list builder
 #define URN_PAIRS_MAX_TABLES 16
 struct PairsDesc { const int *tbl; long ld; int K; const int *n_dev; long n_cap; int T; int *out; int ntiles; };
@@ -45,9 +39,8 @@ __global__ __launch_bounds__(128) void k_pairs_build(PairsDescs ds)
     __shared__ int s_cnt[2];
     const long n_out = d.n_dev ? (long)*d.n_dev : d.n_cap;
     const long row = (long)blockIdx.x * T + tid;
-    const long maxb = (long)K * (T / 16);
-    int *out = d.out + (long)blockIdx.x * pairs_tile_words(K, T);
-    int *out_t = out + URN_PAIRS_HDR, *out_p = out_t + maxb;
+    int *out = d.out + (long)blockIdx.x * urn_pairs_words(K, T);
+    int *out_t = out + URN_PAIRS_HDR, *out_p = out_t + urn_pairs_tpad(K, T);
     int nb = 0;
     for (int t = 0; t < K; ++t) {
         const int v = (tid < T && row < n_out) ? d.tbl[(long)t * d.ld + row] : -1;
@@ -65,6 +58,7 @@ __global__ __launch_bounds__(128) void k_pairs_build(PairsDescs ds)
         const int nblk_t = (total + 15) >> 4;
         if (tid < nblk_t * 16 - total) out_p[(long)nb * 16 + total + tid] = T << 24;   // padding: gather row 0, add into the trash row
         if (tid < nblk_t) out_t[nb + tid] = t;
+        if (tid == 0) ((unsigned char *)(out + 1))[t] = (unsigned char)nb;   // first block of table row t (the weight gradient walks by t)
         nb += nblk_t;
     }
     if (tid == 0) out[0] = nb;
@@ -74,7 +68,7 @@ extern "C" int64_t urn_pairs_bytes(int64_t n_cap, int K, int tile)
 {
     if (n_cap < 0 || K <= 0 || (tile != 32 && tile != 64 && tile != 128)) return -1;
     const int64_t ntiles = (n_cap + tile - 1) / tile;
-    return (ntiles > 0 ? ntiles : 1) * pairs_tile_words(K, tile) * 4;
+    return (ntiles > 0 ? ntiles : 1) * urn_pairs_words(K, tile) * 4;
 }
 
 extern "C" int urn_pairs_build(int n_tables, const int32_t *const *tbl, const int64_t *ld, const int *K,
@@ -139,10 +133,9 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
     if (rows_here <= 0) return;   // workgroup-uniform
 
     const bool ident = g.pairs == nullptr;   // 1x1 convolution on the identity table: blocks of 16 consecutive rows
-    const long maxb = (long)K * (T / 16);
-    const int *hdr = ident ? nullptr : g.pairs + (long)tile * pairs_tile_words(K, T);
+    const int *hdr = ident ? nullptr : g.pairs + (long)tile * urn_pairs_words(K, T);
     const int *blk_t = hdr + URN_PAIRS_HDR;
-    const int *blk_p = blk_t + maxb;
+    const int *blk_p = blk_t + urn_pairs_tpad(K, T);
     const int nblk = ident ? (rows_here + 15) >> 4 : hdr[0];
     const int b0 = nblk * gi / G, b1 = nblk * (gi + 1) / G;   // nblk <= 27 * 8, G <= 16
 

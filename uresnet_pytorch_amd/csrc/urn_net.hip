@@ -18,6 +18,7 @@
 
 int g_dw_group = 1;   // weight gradients per fork to the side stream (urn_set_option "dw_group"); measured: 1: 3.61 ms, 2: 3.66, 4: 3.64, 8: 3.74, 16: 3.85
 
+int g_dw_pairs = 0;        // weight gradients on the two-stage pair-list kernel (bitwise reproducible) instead of the atomics kernel (urn_set_option "dw_pairs")
 int g_net_side_probe = 4;   // candidate side streams tried by an executor's first backward (urn_set_option "net_side_probe"; 0/1 = keep the first)
 int g_net_side_verbose = 0;
 
@@ -108,6 +109,7 @@ struct BNP {
     const float *x = nullptr, *y = nullptr;
     float *mean = nullptr, *invstd = nullptr;
     float *scale = nullptr, *shift = nullptr;   // fused path: relu(x*scale + shift) == BatchNormReLU(x)
+    int64_t nrows = 0;                         // rows of x in the last forward (urn_net_bn_export)
     unsigned long stamp = 0;                   // forward in which the arrays above were carved
 };
 // column partials (sum, sum of squares; fp64) of a tensor, written by its producer's epilogue
@@ -229,6 +231,29 @@ struct urn_net {
         geo.pairs_of(tbl, a.pairs, a.pairs_tile);
         return urn_gconv_fwd_ex(&a, nullptr, st);
     }
+    // weight gradient: on the compacted rule list of the forward table when the geometry carries one (two stages, no
+    // atomics; `scratch` = its partial slab, carved by dw_scratch), else on the dense table (fp32 atomics)
+    void *dw_scratch(const ConvP &c, const int32_t *tbl_f, int64_t n_out)
+    {
+        const int32_t *list; int tile;
+        if (!g_dw_pairs) return nullptr;   // default: the dense-table kernel (fp32 atomics), 1.5-2.5x faster per launch
+        geo.pairs_of(tbl_f, list, tile);
+        if (arena.dry) tile = 64;   // workspace sizing: the lists arrive with the real forward (the size does not depend on the tile)
+        if (!tile || c.cin % 16 || c.cout % 16) return nullptr;
+        return arena.alloc_bytes((size_t)urn_gconv_dw_pairs_scratch_bytes(n_out, tile, c.K, c.cin, c.cout));
+    }
+    int dw_call(const ConvP &c, const BNP *xf, const float *dy, int64_t ld_dy, const int32_t *tbl_f, int64_t n_out, hipStream_t ws,
+                void *scratch)
+    {
+        const int32_t *list; int tile;
+        geo.pairs_of(tbl_f, list, tile);
+        if (scratch && tile)
+            return urn_gconv_bwd_dw_pairs(c.x, 0, xf ? xf->scale : nullptr, xf ? xf->shift : nullptr, dy, ld_dy, list, tile, c.K,
+                                          n_out, c.cin, c.cout, grads + c.w, scratch,
+                                          urn_gconv_dw_pairs_scratch_bytes(n_out, tile, c.K, c.cin, c.cout), ws);
+        return urn_gconv_bwd_dw_strided(c.x, xf ? xf->scale : nullptr, xf ? xf->shift : nullptr, dy, ld_dy > 0 ? ld_dy : c.cout,
+                                        tbl_f, geo.ld, c.K, n_out, c.cin, c.cout, grads + c.w, ws);
+    }
     float *conv_fwd(ConvP &c, const float *x, const int32_t *tbl, int64_t n_out, const float *res)
     {
         c.x = x;
@@ -241,6 +266,7 @@ struct urn_net {
                     int64_t n_in, bool need_dx)
     {
         float *dx = need_dx ? arena.f32(n_in * c.cin) : nullptr;
+        void *scratch = dw_scratch(c, tbl_f, n_out);
         if (live()) {
             if (need_dx) check(gconv_plain(dy, params + c.w, tbl_b, c.K, flip_b, n_in, c.cout, c.cin, nullptr, dx));
             hipStream_t ws = st;
@@ -252,7 +278,7 @@ struct urn_net {
                     side_used = true;
                 }
             }
-            check(urn_gconv_bwd_dw(c.x, dy, tbl_f, geo.ld, c.K, n_out, c.cin, c.cout, grads + c.w, ws));
+            check(dw_call(c, nullptr, dy, 0, tbl_f, n_out, ws, scratch));
         }
         return dx;
     }
@@ -424,6 +450,7 @@ struct urn_net {
             }
         }
         if (xs) alloc_bn(*xf);
+        if (xf) xf->nrows = in.n;
         if (!live()) return y;
         urn_gconv_args a;
         memset(&a, 0, sizeof(a));
@@ -478,7 +505,7 @@ struct urn_net {
     // Weight gradients go to the side stream behind a fork (event record on the main stream, wait on the side stream).
     // They can be queued and forked in groups (g_dw_group > 1) -- measured slower: the later a weight gradient
     // starts, the less of it overlaps with the dX chain -- so the default is one fork per convolution.
-    struct DwJob { ConvP *c; const BNP *xf; const float *dy; const int32_t *tbl_f; int64_t n_out; int64_t ld_dy; };
+    struct DwJob { ConvP *c; const BNP *xf; const float *dy; const int32_t *tbl_f; int64_t n_out; int64_t ld_dy; void *scratch; };
     std::vector<DwJob> dw_queue;
     void dw_flush()
     {
@@ -491,15 +518,12 @@ struct urn_net {
                 side_used = true;
             }
         }
-        for (const DwJob &j : dw_queue)
-            check(urn_gconv_bwd_dw_strided(j.c->x, j.xf ? j.xf->scale : nullptr, j.xf ? j.xf->shift : nullptr, j.dy,
-                                           j.ld_dy > 0 ? j.ld_dy : j.c->cout, j.tbl_f, geo.ld, j.c->K, j.n_out, j.c->cin, j.c->cout,
-                                           grads + j.c->w, ws));
+        for (const DwJob &j : dw_queue) check(dw_call(*j.c, j.xf, j.dy, j.ld_dy, j.tbl_f, j.n_out, ws, j.scratch));
         dw_queue.clear();
     }
-    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out, int64_t ld_dy = 0)
+    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out, int64_t ld_dy, void *scratch)
     {
-        dw_queue.push_back(DwJob{&c, xf, dy, tbl_f, n_out, ld_dy});
+        dw_queue.push_back(DwJob{&c, xf, dy, tbl_f, n_out, ld_dy, scratch});
         if ((int)dw_queue.size() >= g_dw_group) dw_flush();
     }
     // backward of conv(BNReLU_b(x)): returns d/dx (raw input of the BatchNorm), adds `extra` when given
@@ -512,8 +536,9 @@ struct urn_net {
         double *part = acc ? sums_alloc(c.cin) : (double *)arena.alloc_bytes((size_t)urn_gconv_part_bytes(n_in, c.cin));
         float *coef = acc ? nullptr : arena.f32(2 * (int64_t)c.cin);
         float *dx = arena.f32(n_in * c.cin);
+        void *scratch = dw_scratch(c, tbl_f, n_out);
         if (live()) {
-            dw_launch(c, &b, dy, tbl_f, n_out, ld_dy);
+            dw_launch(c, &b, dy, tbl_f, n_out, ld_dy, scratch);
             urn_gconv_args a;
             memset(&a, 0, sizeof(a));
             a.x = dy; a.wt = params + c.w; a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
@@ -791,6 +816,38 @@ static void transpose_all(urn_net *net)
         hipLaunchKernelGGL(k_transpose_all, dim3(32, t.n), dim3(256), 0, net->st, t, net->params, net->wt_all);
     }
 }
+// ---- test hook: the folded BatchNorm+ReLU of the last training forward, per BatchNorm -------------------------------
+// The fused path never writes a normalised tensor; what decides a ReLU mask is relu(x * scale + shift) with the scale /
+// shift the kernels derived.  Parity tests read them back (and the BatchNorm's input x) to pin the oracle's masks to
+// the GPU's: a pre-activation within fp32 rounding of zero otherwise flips between any two evaluation orders.
+extern "C" int urn_net_num_bn(urn_net *net)
+{
+    if (!net) return -1;
+    if (net->all_bns.empty()) { net->collect_bns(net->u); net->all_bns.push_back(&net->bn_out); }
+    return (int)net->all_bns.size();
+}
+extern "C" int urn_net_bn_info(urn_net *net, int i, int64_t *w_off, int64_t *rows, int *c)
+{
+    URN_CHECK_ARG(net && w_off && rows && c && i >= 0 && i < urn_net_num_bn(net), "bad index");
+    const BNP &b = *net->all_bns[i];
+    *w_off = b.w; *rows = b.nrows; *c = b.c;
+    return URN_OK;
+}
+extern "C" int urn_net_bn_export(urn_net *net, int i, float *x, float *scale, float *shift, void *stream)
+{
+    URN_CHECK_ARG(net && x && scale && shift && i >= 0 && i < urn_net_num_bn(net), "bad argument");
+    const BNP &b = *net->all_bns[i];
+    URN_CHECK_ARG(net->fused && b.x && b.scale && b.shift && b.stamp == net->fwd_stamp, "no fused training forward recorded for this BatchNorm");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(x, b.x, (size_t)b.nrows * b.c * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(scale, b.scale, (size_t)b.c * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(shift, b.shift, (size_t)b.c * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        urn_set_error("urn_net_bn_export: copy failed");
+        return URN_EHIP;
+    }
+    return URN_OK;
+}
+
 extern "C" int64_t urn_net_param_count(const urn_net *n) { return n ? n->n_params : -1; }
 extern "C" int64_t urn_net_running_count(const urn_net *n) { return n ? n->n_running : -1; }
 extern "C" int urn_net_num_tensors(const urn_net *n) { return n ? (int)n->p_off.size() : -1; }
@@ -863,7 +920,7 @@ static void run_forward(urn_net *net, const float *site_feats)
         x = net->u_f(net->u, x, 0, c_out);
         // the last BatchNormReLU feeds the OutputLayer, not a conv: materialise it
         BNP &b = net->bn_out;
-        b.x = x.x;
+        b.x = x.x; b.nrows = n0;
         if (x.st.part && net->training) {   // accumulated statistics: the slab is a partial slab of SUM_SLOTS rows
             net->alloc_bn(b);
             if (net->live())

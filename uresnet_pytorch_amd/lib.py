@@ -69,6 +69,9 @@ SIGNATURES = {
                               c_void_p, c_void_p]),
     'urn_gconv_bwd_dw': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p,
                                  c_void_p]),
+    'urn_gconv_dw_pairs_scratch_bytes': (c_i64, [c_i64, c_int, c_int, c_int, c_int]),
+    'urn_gconv_bwd_dw_pairs': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_i64,
+                                       c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
     'urn_transpose_w': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'urn_bn_scratch_bytes': (c_i64, [c_int]),
     'urn_bn_relu_fwd': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
@@ -116,6 +119,9 @@ SIGNATURES = {
     'urn_net_forward': (c_int, [c_void_p, c_int, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_void_p),
                                 ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_i64, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
+    'urn_net_num_bn': (c_int, [c_void_p]),
+    'urn_net_bn_info': (c_int, [c_void_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]),
+    'urn_net_bn_export': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_net_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_set_option': (c_int, [ctypes.c_char_p, c_i64]),
     'urn_prof_enable': (c_int, [c_int]),
