@@ -12,8 +12,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   roofline     -- dominant kernel (gather-conv MFMA kernel, forward + input-gradient launches):
                   algorithmic FLOPs (2*R*Cin*Cout per launch, R = rules of that launch) divided by
                   the kernel's launch durations measured with HIP events on the launch stream;
-  cpu_baseline -- the CPU oracle (oracle/, a port: the reference's own sparse path cannot run
-                  without sparseconvnet) timed on the host cores on one full step of the same event.
+  cpu_baseline -- an SCN-style fp32 CPU restatement (oracle/cpu_port.py, a port: the reference's own sparse path cannot
+                  run without sparseconvnet): per offset gather -> sgemm -> scatter-add on all host cores, forward +
+                  backward of the same event, 2 warm-ups + median of 5.
 """
 import argparse
 import ctypes
@@ -190,17 +191,17 @@ def main():
         }
         cpu = None
         if not args.no_cpu_baseline and world == 1:     # the CPU leg is reported at N=1 only
-            from oracle import sparse_oracle as orc
+            # SCN-style fp32 CPU path (per offset: gather -> sgemm -> scatter-add; oracle/cpu_port.py, checked against the
+            # oracle in tests/test_oracle_sparse.py) on all host threads: 2 warm-ups, median of 5 forward+backward passes
+            # of the SAME event.  (The fp64-accumulating checker oracle/sparse_ref.c is ~10x slower and is not a baseline.)
+            from oracle import cpu_port
             P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if 'running' not in k}
-            ref = orc.SparseUResNetOracle(P, FILTERS, STRIDES, NCLASS, SPATIAL)
-            t1 = time.perf_counter()
-            logits = ref.forward(blob['data'])
-            _, _, dl = orc.segmentation_loss(logits, blob['data'], blob['label'])
-            ref.backward(dl)
-            cdt = time.perf_counter() - t1
-            cpu = {'value': round(voxels_per_rank / cdt, 1), 'unit': 'active-voxels/s',
-                   'cores': int(orc.lib().orc_num_threads()), 'kind': 'port',
-                   'sample': '1 full fwd+bwd step of the same %d-voxel event(s) (%.2f s)' % (voxels_per_rank, cdt)}
+            med, ts, threads = cpu_port.time_step(P, FILTERS, STRIDES, NCLASS, SPATIAL, blob['data'], blob['label'],
+                                                  warmup=2, repeats=5)
+            cpu = {'value': round(voxels_per_rank / med, 1), 'unit': 'active-voxels/s', 'cores': threads, 'kind': 'port',
+                   'sample': '%d-voxel event(s) of the bench, forward+backward, 2 warm-ups + median of 5 (%.3f s; all: %s)'
+                             % (voxels_per_rank, med, ' '.join('%.3f' % t for t in ts)),
+                   'method': 'fp32 per-offset gather -> torch.mm -> scatter-add with the oracle rulebook, torch CPU autograd'}
         result = {
             'metric': 'active-voxels/sec fwd+bwd, 512^3 sparse 5-class U-ResNet', 'value': round(value, 1),
             'unit': 'active-voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

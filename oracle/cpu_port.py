@@ -1,0 +1,120 @@
+"""CPU baseline for bench.py's `cpu_baseline` leg: an SCN-style fp32 restatement of one training step's forward +
+backward of the sparse U-ResNet (reference uresnet/models/uresnet_sparse.py:19-25 + the published body of scn.UNet,
+SURVEY.md App. A) on the host cores.
+
+TEST / MEASUREMENT INFRASTRUCTURE ONLY: nothing under uresnet_pytorch_amd/ imports this module.
+
+How SparseConvNet computes on a CPU (the reference's own CPU path, which cannot run here: the library is absent): the
+rulebook is built on the host, and every convolution is, per filter offset, a gather of the input rows of that offset's
+rules, one dense sgemm with W[offset], and a scatter-add into the output rows; BatchNorm is a pass over the (N, C) row
+matrix.  This module does exactly that with torch CPU ops (index_select -> mm -> index_add_, F.batch_norm), fp32,
+all host threads (torch.get_num_threads()), autograd for the backward pass -- where the numpy/C oracle (sparse_ref.c)
+accumulates in fp64 and is written for checking, not for speed.  The rulebook comes from the oracle's Geometry (the
+integer phase is not what this baseline times: only forward + backward, like the metric).
+
+Its results are checked against the oracle in tests/test_oracle_sparse.py (logits and gradients, 1e-4)."""
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import sparse_oracle as orc
+
+BN_EPS = 1e-4
+
+
+class CpuPort:
+    def __init__(self, params, m, num_strides, num_class, spatial, reps=2):
+        self.P = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(True) for k, v in params.items()}
+        self.m, self.L, self.nc, self.spatial, self.reps = m, num_strides, num_class, spatial, reps
+        self.planes = [i * m for i in range(1, num_strides + 1)]
+
+    # -- geometry: per table, the rules of every offset as (input rows, output rows) index tensors --------------------
+    @staticmethod
+    def _rules(tbl):
+        out = []
+        for o in range(tbl.shape[0]):
+            j = np.nonzero(tbl[o] >= 0)[0]
+            out.append((torch.from_numpy(tbl[o, j].astype(np.int64)), torch.from_numpy(j.astype(np.int64))))
+        return out
+
+    def set_geometry(self, point_cloud):
+        pc = np.asarray(point_cloud)
+        coords = pc[:, :4].astype(np.float32).astype(np.int64).astype(np.int32)
+        feats = pc[:, 4:5].astype(np.float32)
+        g = orc.Geometry(coords, feats, self.spatial, self.L, mode=3)
+        self.n = g.n
+        self.nbr = [self._rules(t) for t in g.nbr]
+        self.chd = [self._rules(t) for t in g.chd]
+        self.up = [self._rules(t) for t in g.up]
+        self.feats = torch.from_numpy(g.feats)
+        self.row2site = torch.from_numpy(g.row2site.astype(np.int64))
+
+    # -- operators -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _conv(x, W, rules, n_out):
+        y = torch.zeros((n_out, W.shape[2]), dtype=torch.float32)
+        for o, (i_in, i_out) in enumerate(rules):
+            if i_in.numel():
+                y = y.index_add(0, i_out, x.index_select(0, i_in) @ W[o])      # gather -> sgemm -> scatter-add
+        return y
+
+    def _bn(self, prefix, x):
+        return F.relu(F.batch_norm(x, None, None, self.P[prefix + '.weight'], self.P[prefix + '.bias'], True, 0.0, BN_EPS))
+
+    def _block(self, prefix, idx, a, b, x, l):
+        p = '%s.%d' % (prefix, idx)
+        sc = x @ self.P[p + '.0.weight'] if a != b else x
+        t = self._conv(self._bn(p + '.1.0', x), self.P[p + '.1.1.weight'], self.nbr[l], self.n[l])
+        t = self._conv(self._bn(p + '.1.2', t), self.P[p + '.1.3.weight'], self.nbr[l], self.n[l])
+        return sc + t
+
+    def _U(self, prefix, l, x):
+        pl = self.planes[l:]
+        idx = 0
+        for _ in range(self.reps):
+            x = self._block(prefix, idx, pl[0], pl[0], x, l); idx += 2
+        if len(pl) > 1:
+            p = '%s.%d.1' % (prefix, idx)
+            t = self._conv(self._bn(p + '.0', x), self.P[p + '.1.weight'], self.chd[l], self.n[l + 1])
+            t = self._U(p + '.2', l + 1, t)
+            t = self._conv(self._bn(p + '.3', t), self.P[p + '.4.weight'], self.up[l], self.n[l])
+            x = torch.cat([x, t], dim=1)
+            idx += 2
+            for i in range(self.reps):
+                x = self._block(prefix, idx, pl[0] * (2 if i == 0 else 1), pl[0], x, l); idx += 2
+        return x
+
+    def forward(self):
+        x = self._conv(self.feats, self.P['sparseModel.1.weight'], self.nbr[0], self.n[0])
+        x = self._U('sparseModel.2', 0, x)
+        x = self._bn('sparseModel.3', x)
+        rows = x.index_select(0, self.row2site)
+        return rows @ self.P['linear.weight'].t() + self.P['linear.bias']
+
+    def step(self, data, label):
+        """forward + loss + backward (gradients land in self.P[*].grad); returns (logits, loss)"""
+        for p in self.P.values():
+            p.grad = None
+        logits = self.forward()
+        bid = torch.from_numpy(np.asarray(data)[:, -2].astype(np.int64))
+        lab = torch.from_numpy(np.asarray(label).reshape(-1).astype(np.int64))
+        ce = F.cross_entropy(logits, lab, reduction='none')
+        loss = sum(ce[bid == b].mean() for b in torch.unique(bid))      # sum over events of the per-event mean
+        loss.backward()
+        return logits.detach(), float(loss.detach())
+
+
+def time_step(params, m, num_strides, num_class, spatial, data, label, warmup=2, repeats=5):
+    """median seconds of `repeats` forward+backward passes after `warmup` untimed ones; (median, all times, threads)"""
+    port = CpuPort(params, m, num_strides, num_class, spatial)
+    port.set_geometry(data)
+    for _ in range(warmup):
+        port.step(data, label)
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        port.step(data, label)
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts, int(torch.get_num_threads())

@@ -76,3 +76,44 @@ def test_two_rank_data_parallel_matches_single_process():
     gref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in net.parameters()])
     assert np.allclose(ga, gref.numpy(), rtol=1e-4, atol=1e-6)
     assert abs(la - total / 2) < 1e-5                 # reported loss = sum over events / batch_size
+
+
+def _uneven_blob():
+    """five events of different sizes in one sub-step: LPT on the pixel counts must balance two ranks"""
+    from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+    b = make_dense_blob([0, 1, 2, 3, 4], 16, 2, 3)
+    return {'data': [[b['data'][i] for i in range(5)]], 'label': [[b['label'][i] for i in range(5)]]}
+
+
+def _worker_lpt(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from uresnet_pytorch_amd.trainval import trainval
+    t = trainval(_flags())
+    t.initialize()
+    res = t.train_step(_uneven_blob(), epoch=0., batch_size=5)
+    p1 = torch.cat([p.detach().flatten() for p in t._net.parameters()]).clone()
+    q.put((rank, list(t.last_slots), p1.numpy(), res['loss_seg']))
+    torch.distributed.destroy_process_group()
+
+
+def test_lpt_sharding_is_used_by_the_trainer_and_replicas_stay_in_sync():
+    from uresnet_pytorch_amd import parallel
+    # the assignment rule itself: largest first onto the least loaded rank, ties by index, per-rank lists sorted
+    assert parallel.shard_events([50, 10, 40, 30, 20], 2) == [[0, 1, 4], [2, 3]]   # loads 80 / 70
+    assert parallel.shard_events([7, 7, 7, 7], 4) == [[0], [1], [2], [3]]
+    assert parallel.shard_events([5], 3) == [[0], [], []]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_lpt, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o[0])
+    for p in procs: p.join(60)
+    (_, s0, pa, la), (_, s1, pb, lb) = outs
+    # five equal-size dense events over two ranks: LPT gives 3 + 2, every event exactly once
+    assert sorted(s0 + s1) == [0, 1, 2, 3, 4] and {len(s0), len(s1)} == {2, 3}
+    assert [s0, s1] == parallel.shard_events([256] * 5, 2)
+    assert np.array_equal(pa, pb)                     # rank-identical parameters after the step
+    assert abs(la - lb) < 1e-12

@@ -199,3 +199,29 @@ def test_param_specs_counts():
     assert total == 2741477
     assert sum(1 for s in specs if s[2] == 'bn_w') == 45
     assert sum(1 for s in specs if s[1][0] == 27) == 37
+
+
+def test_cpu_port_matches_oracle():
+    """oracle/cpu_port.py (the fp32 gather -> sgemm -> scatter-add baseline that bench.py times on the host cores) against
+    the fp64-accumulating oracle: logits, loss and every parameter gradient of a small network."""
+    from oracle import cpu_port
+    from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
+    S, m, L, nc = 32, 16, 3, 5
+    blob = make_sparse_blob([0, 1], S, 600)
+    P = so.init_params(m, L, nc, seed=2)
+    ref = so.SparseUResNetOracle(P, m, L, nc, S)
+    logits_ref = ref.forward(blob['data'])
+    loss_ref, _, dl = so.segmentation_loss(logits_ref, blob['data'], blob['label'])
+    G, _ = ref.backward(dl)
+    port = cpu_port.CpuPort(P, m, L, nc, S)
+    port.set_geometry(blob['data'])
+    logits, loss = port.step(blob['data'], blob['label'])
+
+    def rel(a, b):
+        return float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+    assert rel(logits.numpy(), logits_ref) < 1e-4
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    for k, g in G.items():
+        assert rel(port.P[k].grad.numpy(), g) < 2e-3, (k, rel(port.P[k].grad.numpy(), g))
+    med, ts, threads = cpu_port.time_step(P, m, L, nc, S, blob['data'], blob['label'], warmup=1, repeats=2)
+    assert med > 0 and len(ts) == 2 and threads >= 1

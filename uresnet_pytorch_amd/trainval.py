@@ -38,7 +38,12 @@ class trainval(object):
         self._loss = []
         self._grads.zero()
         total_loss.backward()
-        self._grads.all_reduce()          # SUM over ranks: the reference loss is a sum over all events
+        # SUM over ranks (the reference loss is a sum over all events): ONE collective over the flat buffer, started
+        # asynchronously behind the backward kernels (RCCL waits for the stream's event on its own stream) and joined
+        # right before the optimizer reads the gradients
+        work = self._grads.all_reduce(async_op=True)
+        if work is not None:
+            work.wait()
         self._optimizer.step()
 
     # -- reference trainval.py:32-40
@@ -46,9 +51,14 @@ class trainval(object):
         tstart = time.time()
         filename = '%s-%d.ckpt' % (self._flags.WEIGHT_PREFIX, iteration)
         if self._rank == 0:
+            state = self._net.state_dict()
+            if getattr(self._flags, 'CKPT_MODULE_PREFIX', False):
+                # the reference saves a DataParallel-wrapped module: every key carries 'module.' (reference :37, :181);
+                # with this flag a checkpoint written here loads into the reference with strict=False as well
+                state = {'module.' + k: v for k, v in state.items()}
             torch.save({
                 'global_step': iteration,
-                'state_dict': self._net.state_dict(),
+                'state_dict': state,
                 'optimizer': self._optimizer.state_dict()
             }, filename)
         self.tspent['save'] = time.time() - tstart
@@ -94,18 +104,22 @@ class trainval(object):
         res_combined['loss_seg'] = loss / batch_size
         return res_combined
 
-    def _local_slots(self, n):
-        """Entries of a per-GPU list that this rank owns (contiguous chunks, like the reference's
-        scatter, reference uresnet/ops.py:28-36)."""
-        per = max(1, n // self._world)
-        return list(range(self._rank * per, min(n, (self._rank + 1) * per))) if self._world > 1 else list(range(n))
+    def _local_slots(self, sizes):
+        """Entries of a per-GPU list that this rank owns.  The reference scatters contiguous chunks (uresnet/ops.py:
+        28-36); here whole entries are assigned by greedy LPT on their sizes (active voxels / pixels), so that ranks
+        finish together when events differ in size (parallel.shard_events; deterministic, the same on every rank)."""
+        if self._world <= 1:
+            return list(range(len(sizes)))
+        return parallel.shard_events(sizes, self._world)[self._rank]
 
     # -- reference trainval.py:75-134
     def _forward(self, data_blob, epoch=None):
         data = data_blob['data']
         label = data_blob.get('label', None)
         weight = data_blob.get('weight', None)
-        slots = self._local_slots(len(data))
+        slots = self._local_slots([int(np.asarray(d.shape[0] if hasattr(d, 'shape') and len(d.shape) == 2 else np.prod(np.shape(d))))
+                                   for d in data])
+        self.last_slots = slots
         sparse = 'sparse' in self._flags.MODEL_NAME
         with torch.set_grad_enabled(self._flags.TRAIN):
             data = [torch.as_tensor(data[i]).to(self._device) for i in slots]
