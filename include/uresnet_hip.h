@@ -12,7 +12,8 @@
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the
  *     caller (PyTorch's caching allocator) and borrowed for the duration of the call;
  *   - every launch goes on the hipStream_t passed as `stream` (void*); the library
- *     never synchronises the device and never allocates device memory;
+ *     never synchronises the device (exceptions, both explicit: urn_net_probe, urn_prof_read)
+ *     and never allocates device memory;
  *   - return 0 on success, a negative URN_E* code otherwise, message through
  *     urn_last_error() (thread-local); nothing throws or aborts across the ABI;
  *   - coords rows are (x, y, z, batch) int32; gather tables are [K][ld] int32 with
@@ -327,6 +328,10 @@ int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const int64_t *n, 
                     const float *params, float *running, const float *site_feats, void *ws, int64_t ws_bytes,
                     float *out_rows, int training, void *stream);
 int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stream);
+/* Side-stream probe: the ONE call of the executor that synchronises (`stream` and its candidate streams), therefore
+ * explicit and optional -- once per handle at initialisation.  Keeps the fastest of a few candidate side streams for the
+ * fork/join pattern of the backward pass against `stream` (see urn_net.hip: hardware-queue aliasing). */
+int urn_net_probe(urn_net *net, void *stream);
 
 /* Test hook: the folded BatchNorm+ReLU of the last TRAINING forward on the fused path.  BatchNorm i (0 <= i <
  * urn_net_num_bn, executor order; w_off = offset of its weight in the flat parameter buffer) consumed x (rows, c) as

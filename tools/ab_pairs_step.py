@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
 import numpy as np, torch
-from uresnet_pytorch_amd import lib as L_, parallel
+from uresnet_pytorch_amd import lib as L_, parallel, sparse_ops as so
 from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
 from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
 L = L_.load(); dev = torch.device('cuda:0')
@@ -20,12 +20,12 @@ def run(n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-policies = [('tile only', 0, 0, 0, 6), ('all subm+strided', 999, 999, 0, 7), ('cin<=80', 80, 999, 0, 7), ('all, dwp smax 8', 999, 999, 0, 7, 8), ('all, dwp waves 4096', 999, 999, 0, 7, 16, 4096)]
+policies = [('tile only', 0, 0, 0, 6), ('all subm+strided', 999, 999, 0, 7), ('cin<=80', 80, 999, 0, 7), ('cin<=80,cout<=80', 80, 80, 0, 7), ('all, deterministic dW', 999, 999, 0, 7, 1)]
 res = {p[0]: [] for p in policies}
 for rnd in range(3):
     for name, mi, mo, nin, k, *rest in policies:
-        L.urn_set_option(b'dwp_smax', rest[0] if rest else 16); L.urn_set_option(b'dwp_waves', rest[1] if len(rest) > 1 else 2048)
+        so.set_deterministic_dw(bool(rest[0]) if rest else False)
         L.urn_set_option(b'gconv_kernel', k); L.urn_set_option(b'pairs_max_cin', mi); L.urn_set_option(b'pairs_max_cout', mo); L.urn_set_option(b'pairs_nin', nin)
         res[name].append(run())
 for name, *_ in policies:
-    print('%-20s ms/step min %.3f  all %s' % (name, min(res[name]), ' '.join('%.3f' % v for v in res[name])), flush=True)
+    print('%-24s ms/step min %.3f  all %s' % (name, min(res[name]), ' '.join('%.3f' % v for v in res[name])), flush=True)

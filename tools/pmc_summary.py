@@ -12,7 +12,7 @@ def collect(d, counter):
         if r.get('Counter_Name') != counter:
             continue
         name = r['Kernel_Name']
-        key = 'gconv_fwd_dx' if 'k_gconv_tile' in name else ('k_gconv_dw' if 'k_gconv_dw' in name and 'small' not in name else None)
+        key = 'gconv_fwd_dx' if ('k_gconv_tile' in name or 'k_gconv_pairs' in name) else ('k_gconv_dw' if 'k_gconv_dw' in name and 'small' not in name else None)
         if key is None:
             continue
         a = agg.setdefault(key, [0.0, 0])
@@ -24,7 +24,7 @@ fw = raw['FETCH_SIZE']['gconv_fwd_dx']['avg_kb_per_launch']
 ww = raw['WRITE_SIZE']['gconv_fwd_dx']['avg_kb_per_launch']
 out = {
     'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), python3 bench.py --steps 3 '
-              '--warmup 2 --no-cpu-baseline, MI355X, default kernels (k_gconv_tile interleaved, k_gconv_dw2)',
+              '--warmup 2 --no-cpu-baseline, MI355X, default kernels (k_gconv_pairs / k_gconv_tile by shape, k_gconv_dw2)',
     'raw': raw,
     'correction': 'MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced '
                   '(16 B/lane) read -> doubled; WRITE_SIZE taken as is; counters are KB',

@@ -263,7 +263,7 @@ extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs, g
 // which calls that carry a pair list run on the pair-list kernel (measured per shape on the cfg3 geometry, tools/bench_pairs.py:
 // it wins for the strided pair and the narrow levels; the wide, small levels are faster on the LDS-staged 2-D tile kernel):
 // K == 8, or K == 27 with cin <= g_pairs_max_cin and cout <= g_pairs_max_cout; K == 1 only when g_pairs_nin is set
-static int g_pairs_max_cin = 999, g_pairs_max_cout = 999, g_pairs_nin = 0;
+static int g_pairs_max_cin = 80, g_pairs_max_cout = 999, g_pairs_nin = 0;
 static long g_opt_min_waves = 8192;
 
 extern "C" int urn_set_option(const char *key, int64_t value)

@@ -993,13 +993,27 @@ extern "C" int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const i
     return net->rc;
 }
 
+// Side-stream probe, an explicit call because it SYNCHRONISES (hipStreamSynchronize on `stream` and on the candidate
+// streams): the executor's forward / backward never do.  Times the fork -> concurrent kernels -> join pattern of the
+// backward pass on a few candidate side streams against `stream` and keeps the fastest (HIP multiplexes streams onto a
+// few hardware queues; a side stream that shares its queue with the caller's stream serialises behind it: 9.1 instead of
+// 3.4 ms per step measured).  Call once per handle and caller stream, at initialisation; without it the handle keeps the
+// side stream it was created with.
+extern "C" int urn_net_probe(urn_net *net, void *stream)
+{
+    URN_CHECK_ARG(net, "null handle");
+    if (!net->side || net->side_probed) return URN_OK;
+    net->st = (hipStream_t)stream;
+    net->pick_side();
+    return URN_OK;
+}
+
 // Backward of the last forward on this net (same workspace, same stream): d_rows (n_rows, m) ->
 // grads (flat, ACCUMULATED into; caller zeroes).
 extern "C" int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stream)
 {
     URN_CHECK_ARG(net && d_rows && grads && net->trunk_out, "null pointer or no forward recorded");
     net->grads = grads; net->st = (hipStream_t)stream;
-    if (net->side && !net->side_probed) net->pick_side();
     run_backward(net, d_rows);
     if (net->arena.overflow) { urn_set_error("urn_net_backward: workspace too small (%zu needed)", net->arena.peak); return URN_EINVAL; }
     return net->rc;

@@ -122,6 +122,7 @@ SIGNATURES = {
     'urn_net_num_bn': (c_int, [c_void_p]),
     'urn_net_bn_info': (c_int, [c_void_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]),
     'urn_net_bn_export': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_net_probe': (c_int, [c_void_p, c_void_p]),
     'urn_net_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_set_option': (c_int, [ctypes.c_char_p, c_i64]),
     'urn_prof_enable': (c_int, [c_int]),

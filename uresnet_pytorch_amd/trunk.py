@@ -72,6 +72,10 @@ class TrunkExecutor:
         if with_side:
             _SIDE_HANDLES += 1
             self._side_handles += 1
+            if torch.cuda.is_available():
+                # the one synchronising call of the executor, here at creation (never inside a step): pick a side stream
+                # that does not share a hardware queue with the caller's stream
+                _l.check(L.urn_net_probe(h, _l.stream()), 'net_probe')
         return h
 
     def acquire(self):
@@ -185,7 +189,7 @@ class TrunkExecutor:
         """The workspace need is linear in the level sizes and the row count (every allocation is rows x channels,
         rounded up to 256 B): one dry run per unit vector, cached, replaces a dry run of the whole graph per step --
         that call sat between the level-count synchronisation and the first kernel of the forward pass."""
-        key = (num_levels, int(with_backward))
+        key = (num_levels, int(with_backward), bool(so.DETERMINISTIC_DW))   # (the two-stage weight gradient needs its partial slabs)
         if key not in self._ws_coef:
             L = _l.load()
             U = 1 << 16
