@@ -197,11 +197,14 @@ def main():
             from oracle import cpu_port
             P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if 'running' not in k}
             med, ts, threads = cpu_port.time_step(P, FILTERS, STRIDES, NCLASS, SPATIAL, blob['data'], blob['label'],
-                                                  warmup=2, repeats=5)
+                                                  warmup=2, repeats=5, threads='auto')
             cpu = {'value': round(voxels_per_rank / med, 1), 'unit': 'active-voxels/s', 'cores': threads, 'kind': 'port',
                    'sample': '%d-voxel event(s) of the bench, forward+backward, 2 warm-ups + median of 5 (%.3f s; all: %s)'
                              % (voxels_per_rank, med, ' '.join('%.3f' % t for t in ts)),
-                   'method': 'fp32 per-offset gather -> torch.mm -> scatter-add with the oracle rulebook, torch CPU autograd'}
+                   'method': 'fp32 per-offset gather -> torch.mm -> scatter-add with the oracle rulebook, torch CPU autograd; '
+                             'thread count = fastest of a one-pass sweep: ' +
+                             ', '.join('%d thr %.2f s' % kv for kv in sorted(cpu_port.time_step.last_sweep.items())),
+                   'host_cpus': os.cpu_count()}
         result = {
             'metric': 'active-voxels/sec fwd+bwd, 512^3 sparse 5-class U-ResNet', 'value': round(value, 1),
             'unit': 'active-voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -106,15 +106,37 @@ class CpuPort:
         return logits.detach(), float(loss.detach())
 
 
-def time_step(params, m, num_strides, num_class, spatial, data, label, warmup=2, repeats=5):
-    """median seconds of `repeats` forward+backward passes after `warmup` untimed ones; (median, all times, threads)"""
+def time_step(params, m, num_strides, num_class, spatial, data, label, warmup=2, repeats=5, threads=None):
+    """median seconds of `repeats` forward+backward passes after `warmup` untimed ones; (median, all times, threads).
+    threads=None keeps torch's thread count; 'auto' first times one pass at 8 / 16 / 32 / 64 threads (as far as the host
+    has them) and measures at the fastest: the many small gathers and sgemms of a 50k-voxel event do not scale to 128
+    threads (measured on the GPU box: 19.9 s per step with all 128 threads against well under a second with 8)."""
     port = CpuPort(params, m, num_strides, num_class, spatial)
     port.set_geometry(data)
-    for _ in range(warmup):
-        port.step(data, label)
-    ts = []
-    for _ in range(repeats):
-        t0 = time.perf_counter()
-        port.step(data, label)
-        ts.append(time.perf_counter() - t0)
-    return float(np.median(ts)), ts, int(torch.get_num_threads())
+    before = torch.get_num_threads()
+    sweep = {}
+    if threads == 'auto':
+        import os
+        ncpu = os.cpu_count() or before
+        for c in [c for c in (8, 16, 32, 64) if c <= ncpu] or [before]:
+            torch.set_num_threads(c)
+            port.step(data, label)
+            t0 = time.perf_counter()
+            port.step(data, label)
+            sweep[c] = time.perf_counter() - t0
+        threads = min(sweep, key=sweep.get)
+    if threads:
+        torch.set_num_threads(int(threads))
+    try:
+        for _ in range(warmup):
+            port.step(data, label)
+        ts = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            port.step(data, label)
+            ts.append(time.perf_counter() - t0)
+        used = int(torch.get_num_threads())
+    finally:
+        torch.set_num_threads(before)
+    time_step.last_sweep = sweep
+    return float(np.median(ts)), ts, used
