@@ -296,6 +296,41 @@ int urn_ce_bwd(const float *logits, const float *label, const float *batch_id, i
 int urn_adam_flat(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int64_t step, void *stream);
 
+/* ------------------------------------------------------------------ dense model
+ * Dense 2-D / 3-D convolution family of the dense U-ResNet (reference uresnet/models/uresnet_dense.py:29-83 ResNetModule,
+ * :164-175 ConvTranspose k3 s2 p1 op1, :201-226 forward): implicit GEMM on the matrix cores, the input box of a
+ * workgroup's outputs staged once in LDS, F.pad(mode='replicate') folded into the addressing -- no index tables, no padded
+ * copies.  Activations are channels-last row matrices (batch * Z * Y * X rows of C floats, row stride ld) in fp32;
+ * wt = weights as [tap][cout][cin] fp32 (tap = (kz * kdim[1] + ky) * kdim[2] + kx).  precision 0: fp32 operands
+ * (v_mfma_f32_16x16x4_f32), 1: operands rounded to bf16 in LDS (v_mfma_f32_16x16x16_bf16), fp32 accumulation.
+ * One call computes a sub-grid of the output: out[p + os * u] (u over Sub) = bias + sum over the taps j (nt per dimension)
+ * of wt[tap(wi[.][j])] applied to in[s * u + e[.][j]], out-of-range inputs clamped (mode 0) or skipped (mode 1); dimensions
+ * in z, y, x order, a 2-D volume has Z = 1 and one tap in z.  The four forms of the model (conv forward, its input
+ * gradient on the padded volume, transposed conv forward per output parity class, its input gradient) are geometry
+ * descriptions of this one kernel (uresnet_pytorch_amd/dense_hip.py builds them).  cin, cout multiples of 16. */
+typedef struct {
+    int In[3], Out[3], Sub[3], p[3], os[3], s[3];
+    int nt[3], e[3][3], wi[3][3], kdim[3];
+    int mode;
+} urn_dense_geom;
+/* scratch (urn_dense_conv_scratch_bytes, may be NULL): launches with few output tiles (the deep levels: 4^3 voxels x 512
+ * channels) split the contraction over workgroups into partial outputs there and sum them in a fixed order. */
+int64_t urn_dense_conv_scratch_bytes(int cout, int batch, const urn_dense_geom *geom);
+int urn_dense_conv(const float *x, int64_t ldx, int cin, const float *wt, const float *bias, float *y, int64_t ldy, int cout,
+                   int batch, const urn_dense_geom *geom, int precision, void *scratch, int64_t scratch_bytes, void *stream);
+/* Gradient of F.pad(mode='replicate') (reference uresnet_dense.py:75-80): dx[i] = sum of dxp over the padded positions
+ * that clamp to voxel i.  dxp: rows of the padded volume (dims + pad_lo + pad_hi), dx: rows of the volume; c % 4 == 0. */
+/* Weight gradient of the same convolutions: dw[tap][ci][co] (+)= sum over outputs o of x[in(o, tap)][ci] * dy[o][co] with
+ * in = s * o + tap - lo, clamped (mode 0: the replicate-padded conv) or skipped when out of range (mode 1: the transposed
+ * conv, called with the roles of input and output swapped).  in_dims / out_dims / k / s / lo in z, y, x order.  Two stages,
+ * no atomics: per-share partial sums in `scratch` (urn_dense_dw_scratch_bytes), then dw += the shares in a fixed order. */
+int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, const int *k, int cin, int cout);
+int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *dy, int64_t ld_dy, int cout, int batch, const int *in_dims,
+                 const int *out_dims, const int *k, const int *s, const int *lo, int mode, float *dw, void *scratch,
+                 int64_t scratch_bytes, int precision, void *stream);
+int urn_dense_fold(const float *dxp, float *dx, int batch, const int *dims, const int *pad_lo, const int *pad_hi, int c,
+                   void *stream);
+
 /* ------------------------------------------------------------------ whole-network executor
  * The trunk of the sparse model -- everything between scn.InputLayer and torch.nn.Linear at
  * reference uresnet_sparse.py:19-25 -- run from C++: the same kernels as the per-layer entry

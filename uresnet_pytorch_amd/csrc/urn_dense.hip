@@ -1,0 +1,661 @@
+// Dense 3-D / 2-D convolution family of the dense U-ResNet (reference uresnet/models/uresnet_dense.py:29-83, 164-175,
+// 201-226): implicit GEMM on the matrix cores with the input box of a workgroup's outputs staged ONCE in LDS (a k3
+// convolution reads every input voxel 27 times: from LDS, not from L2), no index tables, no padded copies.
+//
+// Activations are channels-last row matrices (B * Z * Y * X rows, C floats, row stride ld) in fp32; weights come
+// pre-arranged as wt[tap][cout][cin] fp32.  Operands are rounded to bf16 (PREC 1, v_mfma_f32_16x16x16_bf16) or kept in
+// fp32 (PREC 0, v_mfma_f32_16x16x4_f32) while they are parked in LDS; accumulation is fp32.
+//
+// ONE kernel serves the four gather forms of the model.  A launch computes a SUB-GRID of the output volume:
+// out[o] with o_d = p_d + os_d * u_d (u over Sub_d), and per dimension a short list of taps j < nt_d:
+//     in_d = s_d * u_d + e_d[j],     weight tap index w_d[j]
+// with out-of-range in_d either clamped (F.pad(mode='replicate') folded into the addressing) or skipped (zero padding):
+//   A  Conv k{1,3} s{1,2} forward              os 1, s = stride, e = j - pad_lo, w = j, clamp
+//   B  its input gradient on the PADDED input   s1: os 1, s 1, e = -j, w = j, zero;  s2: per parity class of the output
+//      (urn_dense_fold then adds the replicated border back: the gradient of a clamp is a sum)
+//   C  ConvTranspose k3 s2 p1 op1 forward       per parity class c: os 2, p = c, s 1, taps with (c + 1 - t) even, e = (c + 1 - t) / 2, zero
+//   D  its input gradient                       os 1, s 2, e = t - 1, w = t, zero
+// so a stride-2 transposed form is eight dense launches over same-parity outputs, each with only its valid taps.
+//
+// Workgroup = 8 waves, 256 outputs = 16 row blocks of 16 consecutive u_x (TY x TZ row blocks in y, z), up to 64 output
+// columns (grid.y walks wider layers), input channels in chunks of 16*KC that fit the LDS budget.  Per chunk: stage the
+// input box; per tap: the weight tile wt[tap][cols][chunk] is staged (double-buffered, one barrier per tap) and every
+// wave multiplies its 2 row blocks x all column blocks: A fragments are rows of the box shifted by the tap.
+#include "urn_common.h"
+#include <string.h>
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct DenseArgs {
+    const float *x, *wt, *bias;
+    float *y;
+    long ldx, ldy;
+    int cin, cout;
+    int B;
+    int In[3], Out[3], Sub[3], p[3], os[3], s[3];   // z, y, x
+    int nt[3], e[3][3], wi[3][3], kdim[3];
+    int mode;                                       // 0 clamp (replicate), 1 zero (skip)
+    int TY, TZ;                                     // row blocks per workgroup in y and z (TY * TZ == NRB)
+    int NRB;                                        // 16, or 4 for strided inputs (the staged box grows with the stride)
+    int box[3];                                     // staged input box per dim: s * (tile - 1) + (emax - emin) + 1
+    int emin[3];
+    int kc;                                         // 16-channel groups per chunk
+    int cw;                                         // output columns per workgroup (64, 32 or 16)
+    int tg;                                         // taps whose weight tiles are staged together (one barrier pair per group)
+    int zc, zt;                                     // split of the contraction over workgroups (blockIdx.z): chunk slices x tap slices
+    float *slab;                                    // split > 1: partial outputs [z][sub-grid row][cout] instead of y
+    int ntaps;
+    int tap_w[27], tap_box[27];                     // per tap: weight tap index, offset of the tap inside the staged box (voxels)
+};
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+
+template <int PREC>
+__global__ __launch_bounds__(512) void k_dense_conv(DenseArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int ES = PREC ? 2 : 4;                       // bytes per LDS element
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int KC = g.kc, CH = 16 * KC;
+    const int rowb = CH * ES + 16;                         // LDS bytes per box voxel / weight column (+16: bank spread)
+    const int nbox = g.box[0] * g.box[1] * g.box[2];
+    unsigned char *s_box = smem_raw;
+    unsigned char *s_w = smem_raw + (((long)nbox * rowb + 15) & ~15L);   // weight tiles of a group of taps
+
+    // tile position in the sub-grid
+    const int tiles_x = (g.Sub[2] + 15) / 16, tiles_y = (g.Sub[1] + g.TY - 1) / g.TY, tiles_z = (g.Sub[0] + g.TZ - 1) / g.TZ;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int tz = t % tiles_z; const int b = t / tiles_z;
+    const int ux0 = tx * 16, uy0 = ty * g.TY, uz0 = tz * g.TZ;
+    const int col_w0 = blockIdx.y * g.cw;                  // first output column of this workgroup
+    const int ncols = min(g.cw, g.cout - col_w0);          // multiple of 16 (host pads)
+    const int NCB = ncols / 16;
+    const int wtile = ncols * rowb;
+    // origin of the staged box in input coordinates
+    const int iz0 = g.s[0] * uz0 + g.emin[0], iy0 = g.s[1] * uy0 + g.emin[1], ix0 = g.s[2] * ux0 + g.emin[2];
+    const long in_rows_b = (long)b * g.In[0] * g.In[1] * g.In[2];
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the two row blocks of this wave (rb = 2 rp + i -> (ry, rz)) and its column blocks [cb_lo, cb_hi): 16 row blocks =
+    // one pair per wave and all columns; 4 row blocks = two pairs, the column blocks dealt to the waves
+    const int rp = g.NRB == 16 ? wave : (wave & 1);
+    const int cb_lo = g.NRB == 16 ? 0 : (wave >> 1), cb_hi = g.NRB == 16 ? NCB : min(NCB, (wave >> 1) + 1);
+    int ry[2], rz[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int rb = 2 * rp + i; ry[i] = rb % g.TY; rz[i] = rb / g.TY; }
+    int rbase[2];   // box voxel of this lane's row (output u_x = ux0 + r) of either row block, before the tap offset
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rbase[i] = (g.s[0] * rz[i] * g.box[1] + g.s[1] * ry[i]) * g.box[2] + g.s[2] * r;
+
+    // per-tap constants (weight tap index, offset inside the box) come from host-built tables: lane t of a VGPR holds tap
+    // t's, v_readlane fetches them (the first version decoded the tap with integer divisions and indexed the launch
+    // record dynamically: ~3000 scalar instructions and 56 % wait cycles per wave for 54 MFMAs)
+    const int ntaps = g.ntaps;
+    const int v_tap_w = g.tap_w[lane < 27 ? lane : 26], v_tap_box = g.tap_box[lane < 27 ? lane : 26];
+    auto stage_w = [&](int tap, int ch0, int slot) {
+        const int wtap = __builtin_amdgcn_readlane(v_tap_w, tap);   // tile = wt[wtap][col_w0 + c][ch0 .. ch0 + CH)
+        const float *src = g.wt + ((long)wtap * g.cout + col_w0) * g.cin + ch0;
+        unsigned char *dst = s_w + slot * wtile;
+        const int per_log = KC == 4 ? 4 : (KC == 2 ? 3 : 2);
+        const int total = ncols << per_log;
+        for (int base = tid; base < total; base += 4 * nthreads) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(base + u * nthreads, total - 1);
+                v[u] = *(const f32x4 *)(src + (long)(e >> per_log) * g.cin + 4 * (e & ((1 << per_log) - 1)));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = base + u * nthreads;
+                if (e >= total) continue;
+                const int c = e >> per_log, k4 = e & ((1 << per_log) - 1);
+                if constexpr (PREC) {
+                    uint2 pk;
+                    pk.x = f2bf(v[u][0]) | ((unsigned)f2bf(v[u][1]) << 16); pk.y = f2bf(v[u][2]) | ((unsigned)f2bf(v[u][3]) << 16);
+                    *(uint2 *)(dst + c * rowb + 8 * k4) = pk;
+                } else {
+                    *(f32x4 *)(dst + c * rowb + 16 * k4) = v[u];
+                }
+            }
+        }
+    };
+
+    // split contraction: this workgroup's slice of the channel chunks and of the taps (deep levels: few output tiles,
+    // thousands of weights per output -- the slices are summed by k_dense_splitk_reduce in a fixed order)
+    const int nchunks = g.cin / CH;
+    const int zci = blockIdx.z / g.zt, zti = blockIdx.z - zci * g.zt;
+    const int chunk_lo = nchunks * zci / g.zc, chunk_hi = nchunks * (zci + 1) / g.zc;
+    const int tap_lo = ntaps * zti / g.zt, tap_hi = ntaps * (zti + 1) / g.zt;
+    for (int ch0 = chunk_lo * CH; ch0 < chunk_hi * CH; ch0 += CH) {
+        __syncthreads();                                   // the previous chunk's readers are done with the box
+        // stage the input box: voxel (bz, by, bx) of the box = input (iz0 + bz, ...), clamped or zero.  One (bz, by) row of
+        // the box per wave and pass (its index arithmetic is scalar), the lanes walk (bx, 4-channel piece): no integer
+        // division per element.  (A flat index with four loads in flight per thread was measured slower at 128^3 x 16:
+        // 389 vs 295 us; per-element div/mod by the box sizes: 478 us.)
+        {
+            const int per_log = KC == 4 ? 4 : (KC == 2 ? 3 : 2);          // float4 per voxel = 4 KC (KC in {1, 2, 4})
+            const int per = 1 << per_log;
+            const int nrows = g.box[0] * g.box[1], row_elems = g.box[2] << per_log;
+            for (int rowi = wave; rowi < nrows; rowi += nwaves) {
+                const int bz = rowi / g.box[1], by = rowi - bz * g.box[1];
+                int iz = iz0 + bz, iy = iy0 + by;
+                bool okr = true;
+                if (g.mode == 0) { iz = min(max(iz, 0), g.In[0] - 1); iy = min(max(iy, 0), g.In[1] - 1); }
+                else { okr = iz >= 0 && iz < g.In[0] && iy >= 0 && iy < g.In[1]; if (!okr) { iz = 0; iy = 0; } }
+                const float *src_row = g.x + (in_rows_b + ((long)iz * g.In[1] + iy) * g.In[2]) * g.ldx + ch0;
+                unsigned char *dst_row = s_box + (long)rowi * g.box[2] * rowb;
+                for (int e = lane; e < row_elems; e += 64) {
+                    const int bx = e >> per_log, k4 = e & (per - 1);
+                    int ix = ix0 + bx;
+                    bool ok = okr;
+                    if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
+                    else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
+                    f32x4 val = *(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4);
+                    if (!ok) val = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (PREC) {
+                        uint2 pk;
+                        pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
+                        *(uint2 *)(dst_row + bx * rowb + 8 * k4) = pk;
+                    } else {
+                        *(f32x4 *)(dst_row + bx * rowb + 16 * k4) = val;
+                    }
+                }
+            }
+        }
+        // Weight tiles are staged per GROUP of taps (all 27 at once for the narrow layers: their tap loop then runs
+        // without a barrier -- with one barrier per tap a 16-channel layer had 2 MFMAs per wave between barriers)
+        for (int tap0 = tap_lo; tap0 < tap_hi; tap0 += g.tg) {
+            const int tend = min(tap_hi, tap0 + g.tg);
+            if (tap0 != tap_lo) __syncthreads();           // the previous group's readers are done with the tiles
+            for (int tap = tap0; tap < tend; ++tap) stage_w(tap, ch0, tap - tap0);
+            __syncthreads();                               // (also covers the box staged above)
+            for (int tap = tap0; tap < tend; ++tap) {
+                const int tbox = __builtin_amdgcn_readlane(v_tap_box, tap);
+                const unsigned char *wb = s_w + (tap - tap0) * wtile;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    // row r of the block = output (uz0 + rz, uy0 + ry, ux0 + r): box voxel (s rz + dz, s ry + dy, s r + dx)
+                    const unsigned char *arow = s_box + (long)(rbase[i] + tbox) * rowb;
+                    for (int k = 0; k < KC; ++k) {
+                        if constexpr (PREC) {
+                            const s16x4 a = *(const s16x4 *)(arow + 32 * k + 8 * q);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (c >= cb_lo && c < cb_hi) {
+                                    const s16x4 bf = *(const s16x4 *)(wb + (16 * c + r) * rowb + 32 * k + 8 * q);
+                                    acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bf, acc[i][c], 0, 0, 0);
+                                }
+                            }
+                        } else {
+                            const f32x4 a = *(const f32x4 *)(arow + 64 * k + 16 * q);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (c >= cb_lo && c < cb_hi) {
+                                    const f32x4 bf = *(const f32x4 *)(wb + (16 * c + r) * rowb + 64 * k + 16 * q);
+#pragma unroll
+                                    for (int tt = 0; tt < 4; ++tt) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], bf[tt], acc[i][c], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // epilogue: D[row 4q + i][col r]; row = output u_x = ux0 + 4q + i of block (ry, rz)
+    const bool split = g.slab != nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int uz = uz0 + rz[i], uy = uy0 + ry[i];
+        if (uz >= g.Sub[0] || uy >= g.Sub[1]) continue;
+        const int oz = g.p[0] + g.os[0] * uz, oy = g.p[1] + g.os[1] * uy;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < cb_lo || c >= cb_hi) continue;
+            const int col = col_w0 + 16 * c + r;
+            const float bv = (g.bias && !split) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ux = ux0 + 4 * q + k;
+                if (ux >= g.Sub[2]) continue;
+                if (split) {
+                    const long srow = (((long)b * g.Sub[0] + uz) * g.Sub[1] + uy) * g.Sub[2] + ux;
+                    const long nsub = (long)g.B * g.Sub[0] * g.Sub[1] * g.Sub[2];
+                    g.slab[((long)blockIdx.z * nsub + srow) * g.cout + col] = acc[i][c][k];
+                } else {
+                    const int ox = g.p[2] + g.os[2] * ux;
+                    const long row = (long)b * g.Out[0] * g.Out[1] * g.Out[2] + ((long)oz * g.Out[1] + oy) * g.Out[2] + ox;
+                    g.y[row * g.ldy + col] = acc[i][c][k] + bv;
+                }
+            }
+        }
+    }
+}
+
+// y[out row of sub-grid row][col] = bias + slab[0] + slab[1] + ... (fixed order)
+__global__ void k_dense_splitk_reduce(DenseArgs g, int Z)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = g.cout / 4;
+    const long nsub = (long)g.B * g.Sub[0] * g.Sub[1] * g.Sub[2];
+    if (e >= nsub * c4) return;
+    const int k4 = (int)(e % c4);
+    long v = e / c4;
+    const long srow = v;
+    const int ux = (int)(v % g.Sub[2]); v /= g.Sub[2];
+    const int uy = (int)(v % g.Sub[1]); v /= g.Sub[1];
+    const int uz = (int)(v % g.Sub[0]); const int b = (int)(v / g.Sub[0]);
+    f32x4 s = g.bias ? *(const f32x4 *)(g.bias + 4 * k4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < Z; ++z) s += *(const f32x4 *)(g.slab + ((long)z * nsub + srow) * g.cout + 4 * k4);
+    const long row = (long)b * g.Out[0] * g.Out[1] * g.Out[2] +
+                     ((long)(g.p[0] + g.os[0] * uz) * g.Out[1] + (g.p[1] + g.os[1] * uy)) * g.Out[2] + (g.p[2] + g.os[2] * ux);
+    float *dst = g.y + row * g.ldy + 4 * k4;
+    dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2]; dst[3] = s[3];
+}
+
+// split factor of a launch: only when the output tiles alone leave most CUs idle
+static void dense_plan_split(long wgs, int nchunks, int ntaps, int &zc, int &zt)
+{
+    zc = zt = 1;
+    if (wgs >= 384) return;
+    long want = (1024 + wgs - 1) / wgs;       // 64-column workgroups of 8 waves stay (their weight tiles are staged by all
+    if (want > 32) want = 32;                  // threads); the contraction is what gets dealt out
+    zt = (int)(want < ntaps ? want : ntaps);
+    if (zt < 1) zt = 1;
+    long rest = want / zt;
+    zc = (int)(rest < nchunks ? rest : nchunks);
+    if (zc < 1) zc = 1;
+}
+
+extern "C" int64_t urn_dense_conv_scratch_bytes(int cout, int batch, const urn_dense_geom *gm)
+{
+    if (!gm || cout <= 0 || batch <= 0) return -1;
+    const long nsub = (long)batch * gm->Sub[0] * gm->Sub[1] * gm->Sub[2];
+    // split only happens for launches with fewer than 256 workgroups of >= 64 outputs x 16 columns
+    if (nsub * cout / (64 * 16) >= 4096) return 256;
+    return 32 * nsub * cout * 4 + 256;
+}
+
+extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float *wt, const float *bias, float *y, int64_t ldy,
+                              int cout, int batch, const urn_dense_geom *gm, int precision, void *scratch, int64_t scratch_bytes,
+                              void *stream)
+{
+    URN_CHECK_ARG(x && wt && y && gm, "null pointer");
+    URN_CHECK_ARG(cin > 0 && cout > 0 && cin % 16 == 0 && cout % 16 == 0 && batch > 0, "channel counts must be multiples of 16");
+    URN_CHECK_ARG(ldx >= cin && ldy >= cout && ldx % 4 == 0, "row strides");
+    DenseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.ldx = (long)ldx; a.ldy = (long)ldy; a.cin = cin; a.cout = cout; a.B = batch;
+    a.mode = gm->mode;
+    for (int d = 0; d < 3; ++d) {
+        a.In[d] = gm->In[d]; a.Out[d] = gm->Out[d]; a.Sub[d] = gm->Sub[d]; a.p[d] = gm->p[d]; a.os[d] = gm->os[d]; a.s[d] = gm->s[d];
+        a.nt[d] = gm->nt[d]; a.kdim[d] = gm->kdim[d];
+        URN_CHECK_ARG(a.nt[d] >= 1 && a.nt[d] <= 3 && a.Sub[d] >= 0 && a.s[d] >= 1 && a.os[d] >= 1, "bad geometry");
+        int emin = 1 << 30, emax = -(1 << 30);
+        for (int j = 0; j < a.nt[d]; ++j) {
+            a.e[d][j] = gm->e[d][j]; a.wi[d][j] = gm->wi[d][j];
+            emin = a.e[d][j] < emin ? a.e[d][j] : emin; emax = a.e[d][j] > emax ? a.e[d][j] : emax;
+        }
+        a.emin[d] = emin;
+        a.box[d] = emax - emin + 1;   // + s * (tile - 1) below
+    }
+    if (a.Sub[0] == 0 || a.Sub[1] == 0 || a.Sub[2] == 0) return URN_OK;
+    // Tile: 16 row blocks (256 outputs) x 64 columns for the big levels; the deep levels have few voxels and many channels
+    // (16^3 x 128: 16 such tiles for 256 CUs), so the tile shrinks -- 4 row blocks, then 32 and 16 columns -- until the
+    // launch has ~512 workgroups.  4 row blocks also when the input is read with a stride (the staged box grows with it).
+    const bool strided = a.s[0] > 1 || a.s[1] > 1 || a.s[2] > 1;
+    auto tiles_for = [&](int nrb, int &TY, int &TZ) {
+        TY = a.Sub[0] > 1 ? (nrb == 16 ? 4 : 2) : nrb;
+        if (a.Sub[1] < TY) { TY = 1; while (TY * 2 <= a.Sub[1] && TY < nrb) TY *= 2; }
+        TZ = nrb / TY;
+        return (long)((a.Sub[2] + 15) / 16) * ((a.Sub[1] + TY - 1) / TY) * ((a.Sub[0] + TZ - 1) / TZ) * batch;
+    };
+    a.NRB = strided ? 4 : 16; a.cw = 64;
+    {
+        int ty, tz;
+        if (a.NRB == 16 && tiles_for(16, ty, tz) * ((cout + 63) / 64) < 512) a.NRB = 4;
+        (void)tiles_for(a.NRB, a.TY, a.TZ);
+    }
+    a.box[2] += a.s[2] * 15; a.box[1] += a.s[1] * (a.TY - 1); a.box[0] += a.s[0] * (a.TZ - 1);
+    const long nbox = (long)a.box[0] * a.box[1] * a.box[2];
+    const int es = precision ? 2 : 4;
+    // channels per chunk (kc) and taps per weight group (tg): the box plus the group's weight tiles, preferably under
+    // 78 KB (two workgroups per CU), at most 150 KB
+    const int ntaps = a.nt[0] * a.nt[1] * a.nt[2];
+    const long ncols = cout < a.cw ? cout : a.cw;
+    int kc = 0, tg = 0;
+    for (long budget : {78L * 1024, 150L * 1024}) {
+        for (int k = 4; k >= 1 && !kc; k >>= 1) {
+            if ((cin / 16) % k) continue;
+            const long rowb = 16L * k * es + 16;
+            const long boxb = (nbox * rowb + 15) & ~15L;
+            if (boxb + ncols * rowb > budget) continue;
+            long t = (budget - boxb) / (ncols * rowb);
+            kc = k; tg = (int)(t < ntaps ? t : ntaps);
+        }
+        if (kc) break;
+    }
+    if (!kc) { urn_set_error("urn_dense_conv: input box of %ld voxels does not fit LDS", nbox); return URN_EUNSUPPORTED; }
+    a.kc = kc; a.tg = tg; a.ntaps = ntaps;
+    for (int tap = 0; tap < ntaps; ++tap) {
+        const int jx = tap % a.nt[2], jy = (tap / a.nt[2]) % a.nt[1], jz = tap / (a.nt[2] * a.nt[1]);
+        a.tap_w[tap] = (a.wi[0][jz] * a.kdim[1] + a.wi[1][jy]) * a.kdim[2] + a.wi[2][jx];
+        a.tap_box[tap] = ((a.e[0][jz] - a.emin[0]) * a.box[1] + (a.e[1][jy] - a.emin[1])) * a.box[2] + (a.e[2][jx] - a.emin[2]);
+    }
+    const long rowb = 16L * kc * es + 16;
+    const size_t lds = (size_t)(((nbox * rowb + 15) & ~15L) + (long)tg * ncols * rowb);
+    const long tiles = (long)((a.Sub[2] + 15) / 16) * ((a.Sub[1] + a.TY - 1) / a.TY) * ((a.Sub[0] + a.TZ - 1) / a.TZ) * batch;
+    // waves: 16 row blocks = 8 waves (a pair of row blocks each, all column blocks); 4 row blocks = 2 waves per column block
+    const int gy = (cout + a.cw - 1) / a.cw;
+    dense_plan_split(tiles * gy, cin / (16 * kc), ntaps, a.zc, a.zt);
+    const int Z = a.zc * a.zt;
+    const long nsub = (long)batch * a.Sub[0] * a.Sub[1] * a.Sub[2];
+    if (Z > 1 && (!scratch || scratch_bytes < (int64_t)Z * nsub * cout * 4)) { a.zc = a.zt = 1; }   // no scratch: unsplit
+    a.slab = a.zc * a.zt > 1 ? (float *)scratch : nullptr;
+    const dim3 grid((unsigned)tiles, gy, a.zc * a.zt), block(a.NRB == 16 ? 512 : 128 * (int)(ncols / 16));
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_dense_conv<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_dense_conv<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (precision) hipLaunchKernelGGL(k_dense_conv<1>, grid, block, lds, st, a);
+    else hipLaunchKernelGGL(k_dense_conv<0>, grid, block, lds, st, a);
+    if (a.slab)
+        hipLaunchKernelGGL(k_dense_splitk_reduce, dim3(urn_cdiv(nsub * (cout / 4), 256)), dim3(256), 0, st, a, a.zc * a.zt);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// Gradient of the replicate padding: dx[i] = sum of dxp over the padded positions that clamp to i (per dimension the
+// border voxels take their own position plus the pad_lo / pad_hi positions beyond it).  dxp rows: padded volume
+// (In + lo + hi per dim), dx rows: the volume itself; c channels, dense rows.
+__global__ void k_dense_fold(const float *__restrict__ dxp, float *__restrict__ dx, int B, int Z, int Y, int X, int lz, int hz, int ly,
+                             int hy, int lx, int hx, int c)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = c / 4;
+    const long total = (long)B * Z * Y * X * c4;
+    if (e >= total) return;
+    const int k4 = (int)(e % c4);
+    long v = e / c4;
+    const int x = (int)(v % X); v /= X;
+    const int y = (int)(v % Y); v /= Y;
+    const int z = (int)(v % Z); const int b = (int)(v / Z);
+    const int PZ = Z + lz + hz, PY = Y + ly + hy, PX = X + lx + hx;
+    const int z0 = z == 0 ? 0 : z + lz, z1 = z == Z - 1 ? PZ - 1 : z + lz;
+    const int y0 = y == 0 ? 0 : y + ly, y1 = y == Y - 1 ? PY - 1 : y + ly;
+    const int x0 = x == 0 ? 0 : x + lx, x1 = x == X - 1 ? PX - 1 : x + lx;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pz = z0; pz <= z1; ++pz)
+        for (int py = y0; py <= y1; ++py)
+            for (int px = x0; px <= x1; ++px)
+                s += *(const f32x4 *)(dxp + ((((long)b * PZ + pz) * PY + py) * PX + px) * c + 4 * k4);
+    *(f32x4 *)(dx + ((((long)b * Z + z) * Y + y) * X + x) * c + 4 * k4) = s;
+}
+
+extern "C" int urn_dense_fold(const float *dxp, float *dx, int batch, const int *dims /* Z, Y, X */, const int *pad_lo,
+                              const int *pad_hi, int c, void *stream)
+{
+    URN_CHECK_ARG(dxp && dx && dims && pad_lo && pad_hi && c > 0 && c % 4 == 0 && batch > 0, "bad argument");
+    const long total = (long)batch * dims[0] * dims[1] * dims[2] * (c / 4);
+    if (total == 0) return URN_OK;
+    hipLaunchKernelGGL(k_dense_fold, dim3(urn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dxp, dx, batch, dims[0], dims[1],
+                       dims[2], pad_lo[0], pad_hi[0], pad_lo[1], pad_hi[1], pad_lo[2], pad_hi[2], c);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dw[tap][ci][co] = sum over outputs o of x[in(o, tap)][ci] * dy[o][co], in(o, tap) = s * o + tap - lo (clamped: mode 0,
+// or skipped when out of range: mode 1).  The OUTPUT VOXELS are the contraction index of the MFMAs.  A workgroup walks a
+// share of the output tiles (16 u_x * NRB row blocks); per tile it stages the input box (32 input channels) and the dy
+// tile (32 output channels) in LDS once and every wave accumulates the (tap, 16x16 block) products of ITS taps over the
+// tile's voxels in registers; the sums over a share stay in registers and are written once to slab[share] -- a second
+// launch adds the shares in a fixed order (no atomics: bitwise reproducible).
+struct DenseDwArgs {
+    const float *x, *dy;
+    long ldx, ld_dy;
+    int cin, cout, B;
+    int In[3], Out[3], k[3], s[3], lo[3];
+    int mode, TY, TZ, NRB;
+    int box[3];
+    int S;                 // shares (gridDim.x)
+    float *slab;           // [S][ntap][cin][cout]
+};
+
+template <int PREC>
+__global__ __launch_bounds__(512) void k_dense_dw(DenseDwArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int ES = PREC ? 2 : 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int n_ci = (g.cin + 31) / 32;
+    const int cic = blockIdx.y % n_ci, coc = blockIdx.y / n_ci;
+    const int ci0 = cic * 32, co0 = coc * 32;
+    const int NCI = min(2, (g.cin - ci0) / 16), NCO = min(2, (g.cout - co0) / 16);
+    const int rowb = 32 * ES + 16;
+    const int nbox = g.box[0] * g.box[1] * g.box[2];
+    unsigned char *s_box = smem_raw;
+    unsigned char *s_dy = smem_raw + (((long)nbox * rowb + 15) & ~15L);
+    const int ntap = g.k[0] * g.k[1] * g.k[2];
+    const int tiles_x = (g.Out[2] + 15) / 16, tiles_y = (g.Out[1] + g.TY - 1) / g.TY, tiles_z = (g.Out[0] + g.TZ - 1) / g.TZ;
+    const long ntiles = (long)tiles_x * tiles_y * tiles_z * g.B;
+    const long t_lo = ntiles * blockIdx.x / g.S, t_hi = ntiles * (blockIdx.x + 1) / g.S;
+    // this wave's taps: wave, wave + 8, ... (at most 4 for 27 taps); per tap NCI x NCO accumulators
+    f32x4 acc[4][2][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[a][i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (long tile = t_lo; tile < t_hi; ++tile) {
+        long t = tile;
+        const int tx = (int)(t % tiles_x); t /= tiles_x;
+        const int ty = (int)(t % tiles_y); t /= tiles_y;
+        const int tz = (int)(t % tiles_z); const int b = (int)(t / tiles_z);
+        const int ox0 = tx * 16, oy0 = ty * g.TY, oz0 = tz * g.TZ;
+        const int iz0 = g.s[0] * oz0 - g.lo[0], iy0 = g.s[1] * oy0 - g.lo[1], ix0 = g.s[2] * ox0 - g.lo[2];
+        __syncthreads();                                   // readers of the previous tile are done
+        // one (bz, by) row of the box / one row block of the dy tile per wave and pass: scalar index arithmetic, no
+        // integer division per element
+        for (int rowi = wave; rowi < g.box[0] * g.box[1]; rowi += 8) {
+            const int bz = rowi / g.box[1], by = rowi - bz * g.box[1];
+            int iz = iz0 + bz, iy = iy0 + by;
+            bool okr = true;
+            if (g.mode == 0) { iz = min(max(iz, 0), g.In[0] - 1); iy = min(max(iy, 0), g.In[1] - 1); }
+            else { okr = iz >= 0 && iz < g.In[0] && iy >= 0 && iy < g.In[1]; if (!okr) { iz = 0; iy = 0; } }
+            const float *src_row = g.x + ((((long)b * g.In[0] + iz) * g.In[1] + iy) * g.In[2]) * g.ldx + ci0;
+            unsigned char *dst_row = s_box + (long)rowi * g.box[2] * rowb;
+            for (int e = lane; e < g.box[2] * 8; e += 64) {   // 8 float4 per voxel (32 channels)
+                const int bx = e >> 3, k4 = e & 7;
+                int ix = ix0 + bx;
+                bool ok = okr && 4 * k4 < 16 * NCI;
+                if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
+                else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
+                f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok) val = *(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4);
+                if constexpr (PREC) {
+                    uint2 pk;
+                    pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
+                    *(uint2 *)(dst_row + bx * rowb + 8 * k4) = pk;
+                } else {
+                    *(f32x4 *)(dst_row + bx * rowb + 16 * k4) = val;
+                }
+            }
+        }
+        for (int rb = wave; rb < g.NRB; rb += 8) {
+            const int oz = oz0 + rb / g.TY, oy = oy0 + rb % g.TY;
+            const bool okr = oz < g.Out[0] && oy < g.Out[1];
+            const float *src_row = g.dy + ((((long)b * g.Out[0] + (okr ? oz : 0)) * g.Out[1] + (okr ? oy : 0)) * g.Out[2]) * g.ld_dy + co0;
+            for (int e = lane; e < 128; e += 64) {
+                const int vx = e >> 3, k4 = e & 7;
+                const int ox = ox0 + vx;
+                const bool ok = okr && ox < g.Out[2] && 4 * k4 < 16 * NCO;
+                f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok) val = *(const f32x4 *)(src_row + (long)ox * g.ld_dy + 4 * k4);
+                unsigned char *dst = s_dy + (long)(rb * 16 + vx) * rowb;
+                if constexpr (PREC) {
+                    uint2 pk;
+                    pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
+                    *(uint2 *)(dst + 8 * k4) = pk;
+                } else {
+                    *(f32x4 *)(dst + 16 * k4) = val;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int tap = wave + 8 * a;
+            if (tap >= ntap) break;
+            const int dx = tap % g.k[2], dy_ = (tap / g.k[2]) % g.k[1], dz = tap / (g.k[2] * g.k[1]);
+            for (int rb = 0; rb < g.NRB; ++rb) {
+                const int rz = rb / g.TY, ry = rb % g.TY;
+                const int bv0 = ((g.s[0] * rz + dz) * g.box[1] + (g.s[1] * ry + dy_)) * g.box[2] + dx;   // + s * voxel
+                if constexpr (PREC) {
+                    s16x4 af[2], bf[2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int vx = 4 * q + j;
+                        const unsigned char *xr = s_box + (long)(bv0 + g.s[2] * vx) * rowb;
+                        const unsigned char *dr = s_dy + (long)(rb * 16 + vx) * rowb;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            af[i][j] = *(const short *)(xr + 2 * (16 * i + r));
+                            bf[i][j] = *(const short *)(dr + 2 * (16 * i + r));
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (i < NCI && c < NCO) acc[a][i][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[i], bf[c], acc[a][i][c], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int vx = 4 * m + q;
+                        const unsigned char *xr = s_box + (long)(bv0 + g.s[2] * vx) * rowb;
+                        const unsigned char *dr = s_dy + (long)(rb * 16 + vx) * rowb;
+                        float af[2], bf[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) { af[i] = *(const float *)(xr + 4 * (16 * i + r)); bf[i] = *(const float *)(dr + 4 * (16 * i + r)); }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+                                if (i < NCI && c < NCO) acc[a][i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[c], acc[a][i][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // D[row 4q + k][col r] of (tap, i, c) = dw[tap][ci0 + 16 i + 4q + k][co0 + 16 c + r]
+    float *out = g.slab + (long)blockIdx.x * ntap * g.cin * g.cout;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int tap = wave + 8 * a;
+        if (tap >= ntap) break;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (i >= NCI || c >= NCO) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    out[((long)tap * g.cin + ci0 + 16 * i + 4 * q + k) * g.cout + co0 + 16 * c + r] = acc[a][i][c][k];
+            }
+    }
+}
+
+__global__ void k_dense_dw_reduce(const float *__restrict__ slab, int S, long n, float *__restrict__ dw)
+{
+    const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= n) return;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        f32x4 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = *(const f32x4 *)(slab + (long)(s + k) * n + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += p[k];
+    }
+    for (; s < S; ++s) v += *(const f32x4 *)(slab + (long)s * n + e);
+    *(f32x4 *)(dw + e) += v;
+}
+
+extern "C" int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, const int *k, int cin, int cout)
+{
+    if (!out_dims || !k || cin <= 0 || cout <= 0) return -1;
+    const long ntap = (long)k[0] * k[1] * k[2];
+    const long tiles = (long)((out_dims[2] + 15) / 16) * out_dims[1] * out_dims[0] * batch;   // upper bound on the tile count
+    long S = tiles < 256 ? tiles : 256;
+    if (S < 1) S = 1;
+    return S * ntap * cin * cout * 4 + 256;
+}
+
+extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *dy, int64_t ld_dy, int cout, int batch,
+                            const int *in_dims, const int *out_dims, const int *k, const int *s, const int *lo, int mode,
+                            float *dw, void *scratch, int64_t scratch_bytes, int precision, void *stream)
+{
+    URN_CHECK_ARG(x && dy && dw && scratch && in_dims && out_dims && k && s && lo, "null pointer");
+    URN_CHECK_ARG(cin > 0 && cout > 0 && cin % 16 == 0 && cout % 16 == 0 && batch > 0 && ldx >= cin && ld_dy >= cout && ldx % 4 == 0 && ld_dy % 4 == 0,
+                  "channel counts must be multiples of 16");
+    DenseDwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.ldx = (long)ldx; a.ld_dy = (long)ld_dy; a.cin = cin; a.cout = cout; a.B = batch; a.mode = mode;
+    int ntap = 1;
+    for (int d = 0; d < 3; ++d) {
+        a.In[d] = in_dims[d]; a.Out[d] = out_dims[d]; a.k[d] = k[d]; a.s[d] = s[d]; a.lo[d] = lo[d];
+        URN_CHECK_ARG(k[d] >= 1 && k[d] <= 3 && s[d] >= 1 && s[d] <= 2 && out_dims[d] >= 1 && in_dims[d] >= 1, "bad geometry");
+        ntap *= k[d];
+    }
+    // row blocks per tile: 16 for stride 1, 4 for stride 2 (the staged box grows with the stride)
+    const int stride = (s[0] > 1 || s[1] > 1 || s[2] > 1) ? 2 : 1;
+    a.NRB = stride == 1 ? 16 : 4;
+    a.TY = a.Out[0] > 1 ? (a.NRB == 16 ? 4 : 2) : a.NRB;
+    if (a.Out[1] < a.TY) { a.TY = 1; while (a.TY * 2 <= a.Out[1] && a.TY < a.NRB) a.TY *= 2; }
+    a.TZ = a.NRB / a.TY;
+    a.box[2] = a.s[2] * 15 + a.k[2]; a.box[1] = a.s[1] * (a.TY - 1) + a.k[1]; a.box[0] = a.s[0] * (a.TZ - 1) + a.k[0];
+    const long nbox = (long)a.box[0] * a.box[1] * a.box[2];
+    const int es = precision ? 2 : 4;
+    const long rowb = 32L * es + 16;
+    const size_t lds = (size_t)(((nbox * rowb + 15) & ~15L) + (long)a.NRB * 16 * rowb);
+    if (lds > 160 * 1024) { urn_set_error("urn_dense_dw: staged box of %ld voxels does not fit LDS", nbox); return URN_EUNSUPPORTED; }
+    const long ntiles = (long)((a.Out[2] + 15) / 16) * ((a.Out[1] + a.TY - 1) / a.TY) * ((a.Out[0] + a.TZ - 1) / a.TZ) * batch;
+    long S = ntiles < 256 ? ntiles : 256;
+    if (S < 1) S = 1;
+    const long n = (long)ntap * cin * cout;
+    URN_CHECK_ARG(scratch_bytes >= S * n * 4, "scratch smaller than urn_dense_dw_scratch_bytes");
+    a.S = (int)S; a.slab = (float *)scratch;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_dense_dw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_dense_dw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)S, ((cin + 31) / 32) * ((cout + 31) / 32)), block(512);
+    if (precision) hipLaunchKernelGGL(k_dense_dw<1>, grid, block, lds, st, a);
+    else hipLaunchKernelGGL(k_dense_dw<0>, grid, block, lds, st, a);
+    hipLaunchKernelGGL(k_dense_dw_reduce, dim3(urn_cdiv((n + 3) / 4, 256)), dim3(256), 0, st, (const float *)scratch, (int)S, n, dw);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}

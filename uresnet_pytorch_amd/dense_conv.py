@@ -1,0 +1,272 @@
+"""Dense convolutions of the dense U-ResNet on the implicit-GEMM kernel (csrc/urn_dense.hip), through the C ABI.
+
+Replaces, for GPU tensors, what the reference asks of torch/cuDNN (reference uresnet/models/uresnet_dense.py):
+  F.pad(mode='replicate') + nn.Conv{2,3}d k{1,3} s{1,2}   (:38-67, 75-80, 128-134, 179-197)   -> conv()
+  nn.ConvTranspose{2,3}d k3 s2 p1 op1                      (:165-172)                          -> conv_transpose()
+Activations are channels-last row matrices (B * Z * Y * X rows, C columns, fp32); nothing is padded or tabulated: the
+replicate clamp lives in the kernel's addressing, the four gather forms (forward, input gradient, transposed forward,
+its input gradient) are geometry descriptions of ONE kernel (urn_dense_geom), and the weight gradient is its own kernel.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _l
+
+PRECISION = 0        # 0 fp32 operands, 1 bf16 operands (fp32 accumulate); set_precision()
+
+
+def set_precision(name):
+    global PRECISION
+    PRECISION = {'fp32': 0, 'bf16': 1}[name]
+
+
+def _dims3(spatial):
+    """spatial dims (2 or 3 of them) -> [Z, Y, X] with Z = 1 for 2-D"""
+    return [1] * (3 - len(spatial)) + list(spatial)
+
+
+def _geom(In, Out, Sub, p, os, s, taps, kdim, mode):
+    """taps: per dim list of (e, w)"""
+    g = _l.DenseGeom()
+    for d in range(3):
+        g.In[d], g.Out[d], g.Sub[d], g.p[d], g.os[d], g.s[d] = In[d], Out[d], Sub[d], p[d], os[d], s[d]
+        g.nt[d] = len(taps[d]); g.kdim[d] = kdim[d]
+        for j, (e, w) in enumerate(taps[d]):
+            g.e[d][j] = e; g.wi[d][j] = w
+    g.mode = mode
+    return g
+
+
+_SCRATCH = {}
+
+
+def _launch(x, ldx, cin, wt, bias, y, ldy, cout, B, g):
+    L = _l.load()
+    sb = L.urn_dense_conv_scratch_bytes(cout, B, ctypes.byref(g))
+    key = (x.device, sb > 256)
+    scratch = _SCRATCH.get(key)
+    if scratch is None or scratch.numel() < sb:
+        # split-contraction slabs of the small launches (same stream: reuse is ordered); the big launches never split
+        scratch = _SCRATCH[key] = torch.empty(max(sb, 256), dtype=torch.uint8, device=x.device)
+    _l.check(L.urn_dense_conv(x.data_ptr(), ldx, cin, wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), ldy,
+                              cout, B, ctypes.byref(g), PRECISION, scratch.data_ptr(), scratch.numel(), _l.stream()), 'dense_conv')
+
+
+def _colsum(rows, c):
+    """column sums of the first c columns of a row matrix (bias gradient): the BatchNorm statistics kernel (fp64 partials
+    per workgroup, summed here) instead of a torch reduction over 2M x 16 elements (1.6 ms at 128^3)"""
+    L = _l.load()
+    rows = rows.contiguous()
+    n, cp = rows.shape
+    part = torch.empty(L.urn_bn_scratch_bytes(cp) // 8, dtype=torch.float64, device=rows.device)
+    n_part = ctypes.c_int(0)
+    _l.check(L.urn_bn_stats_partial(rows.data_ptr(), n, cp, part.data_ptr(), ctypes.byref(n_part), _l.stream()), 'bn_stats_partial')
+    return part[:n_part.value * 2 * cp].reshape(n_part.value, 2, cp)[:, 0, :c].sum(0).float()
+
+
+def _pad16(t, dim):
+    n = t.shape[dim]
+    padn = (-n) % 16
+    if not padn:
+        return t
+    shape = list(t.shape); shape[dim] = padn
+    return torch.cat([t, t.new_zeros(shape)], dim=dim)
+
+
+def conv_geoms(spatial, k, stride, pad_lo, pad_hi):
+    """forward geometry of Conv k s on the replicate-padded volume, and the geometries of its input gradient on the
+    PADDED volume (one per parity class for stride 2).  Returns (out_spatial3, fwd, [bwd...], padded3)."""
+    nd = len(spatial)
+    In = _dims3(spatial)
+    real = [False] * (3 - nd) + [True] * nd
+    kk = [k if r else 1 for r in real]
+    ss = [stride if r else 1 for r in real]
+    lo = [pad_lo if r else 0 for r in real]
+    hi = [pad_hi if r else 0 for r in real]
+    Pd = [In[d] + lo[d] + hi[d] for d in range(3)]
+    Out = [(Pd[d] - kk[d]) // ss[d] + 1 for d in range(3)]
+    fwd = _geom(In, Out, Out, [0] * 3, [1] * 3, ss, [[(j - lo[d], j) for j in range(kk[d])] for d in range(3)], kk, 0)
+    # input gradient: dxp[pp] = sum_t dy[(pp - t) / s] W[t]^T where divisible and in range (zero mode)
+    bwd = []
+    if stride == 1:
+        bwd.append(_geom(Out, Pd, Pd, [0] * 3, [1] * 3, [1] * 3, [[(-j, j) for j in range(kk[d])] for d in range(3)], kk, 1))
+    else:
+        def classes(d):
+            if not real[d]:
+                return [(0, 1, [(0, 0)])]                      # (parity origin, output step, taps)
+            out = []
+            for c in range(2):
+                # pp = 2u + c, o = (pp - t) / 2 = u + (c - t) / 2
+                taps = [((c - t) // 2, t) for t in range(kk[d]) if (c - t) % 2 == 0]
+                out.append((c, 2, taps))
+            return out
+        for cz in classes(0):
+            for cy in classes(1):
+                for cx in classes(2):
+                    cls = [cz, cy, cx]
+                    if any(len(c[2]) == 0 for c in cls):
+                        continue                                   # no tap reaches this class: stays zero
+                    Sub = [(Pd[d] - cls[d][0] + cls[d][1] - 1) // cls[d][1] for d in range(3)]
+                    bwd.append(_geom(Out, Pd, Sub, [c[0] for c in cls], [c[1] for c in cls], [1] * 3, [c[2] for c in cls], kk, 1))
+    return Out, fwd, bwd, (In, Pd, lo, hi)
+
+
+def convT_geoms(spatial):
+    """ConvTranspose k3 s2 p1 op1: forward = one geometry per output parity class; input gradient = one geometry."""
+    nd = len(spatial)
+    In = _dims3(spatial)
+    real = [False] * (3 - nd) + [True] * nd
+    Out = [2 * In[d] if real[d] else 1 for d in range(3)]
+    kk = [3 if r else 1 for r in real]
+
+    def classes(d):
+        if not real[d]:
+            return [(0, 1, [(0, 0)])]
+        # o = 2u + c, j = (o + 1 - t) / 2 = u + (c + 1 - t) / 2
+        return [(c, 2, [((c + 1 - t) // 2, t) for t in range(3) if (c + 1 - t) % 2 == 0]) for c in range(2)]
+    fwd = []
+    for cz in classes(0):
+        for cy in classes(1):
+            for cx in classes(2):
+                cls = [cz, cy, cx]
+                fwd.append(_geom(In, Out, In, [c[0] for c in cls], [c[1] for c in cls], [1] * 3, [c[2] for c in cls], kk, 1))
+    # dIn[j] = sum_t dOut[2j - 1 + t] w[t]^T
+    bwd = _geom(Out, In, In, [0] * 3, [1] * 3, [2 if r else 1 for r in real],
+                [[(t - 1, t) for t in range(kk[d])] if real[d] else [(0, 0)] for d in range(3)], kk, 1)
+    return Out, fwd, bwd
+
+
+class DenseConvFunction(torch.autograd.Function):
+    """y rows = Conv(k, stride) of the replicate-padded volume (+ bias).  rows: (B * prod(spatial), Cin)."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias, B, spatial, stride, pad_lo, pad_hi):
+        _l.require_gpu(rows)
+        rows = rows.contiguous()
+        nd = len(spatial)
+        k = weight.shape[2]
+        cout, cin = weight.shape[0], weight.shape[1]
+        Out, fwd, bwd, padinfo = conv_geoms(spatial, k, stride, pad_lo, pad_hi)
+        # weights as [tap][cout][cin], channel counts zero-padded to multiples of 16 (the 1-channel input conv, the
+        # num_class-channel output conv)
+        wt = weight.reshape(cout, cin, -1).permute(2, 0, 1).contiguous()
+        wt = _pad16(_pad16(wt, 1), 2)
+        xin = _pad16(rows, 1)
+        cin_p, cout_p = wt.shape[2], wt.shape[1]
+        bias_p = None if bias is None else _pad16(bias.contiguous(), 0)
+        n_out = B * Out[0] * Out[1] * Out[2]
+        y = torch.empty((n_out, cout_p), dtype=torch.float32, device=rows.device)
+        _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, fwd)
+        ctx.save_for_backward(xin, weight)
+        ctx.meta = (B, tuple(spatial), stride, Out, bwd, padinfo, cin, cout, cin_p, cout_p, bias is not None)
+        ctx.out_spatial = tuple(Out[3 - nd:])
+        return y[:, :cout].contiguous() if cout_p != cout else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, weight = ctx.saved_tensors
+        B, spatial, stride, Out, bwd, (In, Pd, lo, hi), cin, cout, cin_p, cout_p, has_bias = ctx.meta
+        L = _l.load()
+        dy = _pad16(dy.contiguous(), 1)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dxp[pp][ci] = sum dy[o][co] W[co][ci][t]: weights as [tap][ci][co]
+            wb = weight.reshape(cout, cin, -1).permute(2, 1, 0).contiguous()
+            wb = _pad16(_pad16(wb, 1), 2)
+            n_p = B * Pd[0] * Pd[1] * Pd[2]
+            full = stride == 1 or len(bwd) == 2 ** len(spatial)      # every padded position is written by some launch
+            dxp = (torch.empty if full else torch.zeros)((n_p, cin_p), dtype=torch.float32, device=dy.device)
+            for g in bwd:
+                _launch(dy, cout_p, cout_p, wb, None, dxp, cin_p, cin_p, B, g)
+            if any(lo) or any(hi):
+                dxf = torch.empty((B * In[0] * In[1] * In[2], cin_p), dtype=torch.float32, device=dy.device)
+                I3 = ctypes.c_int * 3
+                _l.check(L.urn_dense_fold(dxp.data_ptr(), dxf.data_ptr(), B, I3(*In), I3(*lo), I3(*hi), cin_p, _l.stream()),
+                         'dense_fold')
+            else:
+                dxf = dxp
+            dx = dxf[:, :cin].contiguous() if cin_p != cin else dxf
+        if ctx.needs_input_grad[1]:
+            dw = dense_conv_dw(xin, dy, weight.shape, B, spatial, stride, lo, Out, cin, cout)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, cout)
+        return dx, dw, db, None, None, None, None, None
+
+
+def _dw_call(x, cx, dy, cy, B, in_dims, out_dims, kk, ss, lo, mode):
+    """dw[tap][cx][cy] = sum_o x[in(o, tap)] (x) dy[o]  (two stages, deterministic); returns the (ntap, cx, cy) tensor"""
+    L = _l.load()
+    I3 = ctypes.c_int * 3
+    ntap = kk[0] * kk[1] * kk[2]
+    dwt = torch.zeros((ntap, cx, cy), dtype=torch.float32, device=x.device)
+    sb = L.urn_dense_dw_scratch_bytes(B, I3(*out_dims), I3(*kk), cx, cy)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+    _l.check(L.urn_dense_dw(x.data_ptr(), cx, cx, dy.data_ptr(), cy, cy, B, I3(*in_dims), I3(*out_dims), I3(*kk), I3(*ss),
+                            I3(*lo), mode, dwt.data_ptr(), scratch.data_ptr(), sb, PRECISION, _l.stream()), 'dense_dw')
+    return dwt
+
+
+def dense_conv_dw(xin, dy, wshape, B, spatial, stride, lo, Out, cin, cout):
+    """weight gradient of the padded convolution; xin (rows, cin_p), dy (rows_out, cout_p), both zero-padded to 16"""
+    nd = len(spatial)
+    k = wshape[2]
+    In = _dims3(spatial)
+    real = [False] * (3 - nd) + [True] * nd
+    kk = [k if r else 1 for r in real]
+    ss = [stride if r else 1 for r in real]
+    dwt = _dw_call(xin, xin.shape[1], dy, dy.shape[1], B, In, Out, kk, ss, lo, 0)
+    # [tap][ci][co] -> torch layout (cout, cin, *k)
+    return dwt[:, :cin, :cout].permute(2, 1, 0).reshape(wshape).contiguous()
+
+
+class DenseConvTransposeFunction(torch.autograd.Function):
+    """y rows = ConvTranspose k3 s2 p1 op1 (+ bias); weight (Cin, Cout, *k) like torch."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias, B, spatial):
+        _l.require_gpu(rows)
+        rows = rows.contiguous()
+        nd = len(spatial)
+        cin, cout = weight.shape[0], weight.shape[1]
+        Out, fwd, bwd = convT_geoms(spatial)
+        wt = weight.reshape(cin, cout, -1).permute(2, 1, 0).contiguous()            # [tap][cout][cin]
+        wt = _pad16(_pad16(wt, 1), 2)
+        xin = _pad16(rows, 1)
+        cin_p, cout_p = wt.shape[2], wt.shape[1]
+        bias_p = None if bias is None else _pad16(bias.contiguous(), 0)
+        y = torch.empty((B * Out[0] * Out[1] * Out[2], cout_p), dtype=torch.float32, device=rows.device)
+        for g in fwd:
+            _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, g)
+        ctx.save_for_backward(xin, weight)
+        ctx.meta = (B, tuple(spatial), Out, bwd, cin, cout, cin_p, cout_p, bias is not None)
+        ctx.out_spatial = tuple(Out[3 - nd:])
+        return y[:, :cout].contiguous() if cout_p != cout else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, weight = ctx.saved_tensors
+        B, spatial, Out, bwd, cin, cout, cin_p, cout_p, has_bias = ctx.meta
+        L = _l.load()
+        nd = len(spatial)
+        dy = _pad16(dy.contiguous(), 1)
+        dx = dw = db = None
+        In = _dims3(spatial)
+        if ctx.needs_input_grad[0]:
+            wb = weight.reshape(cin, cout, -1).permute(2, 0, 1).contiguous()          # [tap][cin][cout]: kernel cout = cin
+            wb = _pad16(_pad16(wb, 1), 2)
+            dxf = torch.empty((B * In[0] * In[1] * In[2], cin_p), dtype=torch.float32, device=dy.device)
+            _launch(dy, cout_p, cout_p, wb, None, dxf, cin_p, cin_p, B, bwd)
+            dx = dxf[:, :cin].contiguous() if cin_p != cin else dxf
+        if ctx.needs_input_grad[1]:
+            # dW[ci][co][t] = sum_j x[j][ci] dy[2j - 1 + t][co]: the weight gradient of a stride-2 conv with the roles of
+            # input and output swapped (dy is the "input" volume, x the "output" rows), pad_lo 1
+            real = [False] * (3 - nd) + [True] * nd
+            kk = [3 if r else 1 for r in real]
+            ss = [2 if r else 1 for r in real]
+            lo = [1 if r else 0 for r in real]
+            dwt = _dw_call(dy, cout_p, xin, cin_p, B, Out, In, kk, ss, lo, 1)
+            dw = dwt[:, :cout, :cin].permute(2, 1, 0).reshape(weight.shape).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, cout)
+        return dx, dw, db, None, None

@@ -38,6 +38,13 @@ class GConvArgs(ctypes.Structure):
                 ('ldx', ctypes.c_int64), ('ldy', ctypes.c_int64), ('pairs', ctypes.c_void_p), ('pairs_tile', ctypes.c_int)]
 
 
+class DenseGeom(ctypes.Structure):
+    """urn_dense_geom of include/uresnet_hip.h (dimensions in z, y, x order)"""
+    _fields_ = [('In', ctypes.c_int * 3), ('Out', ctypes.c_int * 3), ('Sub', ctypes.c_int * 3), ('p', ctypes.c_int * 3),
+                ('os', ctypes.c_int * 3), ('s', ctypes.c_int * 3), ('nt', ctypes.c_int * 3), ('e', (ctypes.c_int * 3) * 3),
+                ('wi', (ctypes.c_int * 3) * 3), ('kdim', ctypes.c_int * 3), ('mode', ctypes.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/uresnet_hip.h
 SIGNATURES = {
     'urn_version': (c_int, []),
@@ -106,6 +113,13 @@ SIGNATURES = {
                            c_void_p]),
     'urn_ce_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
                            c_void_p, c_void_p]),
+    'urn_dense_conv_scratch_bytes': (c_i64, [c_int, c_int, c_void_p]),
+    'urn_dense_conv': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_void_p,
+                               c_i64, c_void_p]),
+    'urn_dense_dw_scratch_bytes': (c_i64, [c_int, c_void_p, c_void_p, c_int, c_int]),
+    'urn_dense_dw': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_int, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    'urn_dense_fold': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'urn_net_create': (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, c_int, ctypes.POINTER(c_void_p)]),
     'urn_net_destroy': (None, [c_void_p]),
     'urn_net_param_count': (c_i64, [c_void_p]),

@@ -121,8 +121,11 @@ class UResNet(nn.Module):
     def forward(self, input):
         """input (B, C, (N,)*dim) -> logits (B, num_classes, (N,)*dim), no softmax."""
         if input.is_cuda:
-            from .. import lib as _lib
-            _lib.set_precision(getattr(self._flags, 'PRECISION', 'fp32'))   # flags -prec: fp32 (default) | bf16 | fp16
+            from .. import dense_conv as _dc
+            prec = getattr(self._flags, 'PRECISION', 'fp32')                # flags -prec: fp32 (default) | bf16
+            if prec not in ('fp32', 'bf16'):
+                raise RuntimeError('dense kernels: MFMA operand precision fp32 or bf16 (got %s)' % prec)
+            _dc.set_precision(prec)
         conv_feature_map = {}
         net = _conv_bn(self.conv1, input, relu=True)
         conv_feature_map[net.size()[1]] = net            # skip links keyed by channel count (reference :210,214)
