@@ -244,6 +244,153 @@ __global__ __launch_bounds__(512) void k_dense_conv(DenseArgs g)
     }
 }
 
+// ---- fast path: 3 x 3 x 3 taps, unit strides, 16 row blocks (tile 16 x 4 x 4, box 18 x 6 x 6) ----------------------------
+// The big levels of the dense model are k3 s1 convolutions (forward: e = j - 1, clamp; input gradient on the padded volume:
+// e = -j, zero).  With the tile fixed, every LDS offset of the tap loop is a compile-time constant: the loop is 27 x (A
+// fragments of the wave's two row blocks + NCB weight fragments + MFMAs) and nothing else.  The generic kernel spent
+// ~1450 scalar and ~1900 vector instructions per wave on loop bookkeeping for 54 MFMAs at 16 channels -- the scalar unit of
+// a CU alone was busy for half of the kernel's time (PMC: SQ_INSTS_SALU).  REV: tap j reads box offset 2 - j (the input
+// gradient's e = -j) instead of j.  Weight tiles are staged one z-slice (9 taps) at a time.
+template <int PREC, int KC, int NCB, int REV>
+__global__ __launch_bounds__(512) void k_dense_conv3(DenseArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int ES = PREC ? 2 : 4, CH = 16 * KC, ROWB = CH * ES + 16;
+    constexpr int BX = 18, BY = 6, BZ = 6, NBOX = BX * BY * BZ;
+    constexpr int NCOLS = 16 * NCB, WTILE = NCOLS * ROWB;
+    constexpr int PER_LOG = KC == 4 ? 4 : (KC == 2 ? 3 : 2), PER = 1 << PER_LOG;
+    unsigned char *s_box = smem_raw;
+    unsigned char *s_w = smem_raw + ((NBOX * ROWB + 15) & ~15);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int tiles_x = (g.Sub[2] + 15) / 16, tiles_y = (g.Sub[1] + 3) / 4, tiles_z = (g.Sub[0] + 3) / 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int tz = t % tiles_z; const int b = t / tiles_z;
+    const int ux0 = tx * 16, uy0 = ty * 4, uz0 = tz * 4;
+    const int col_w0 = blockIdx.y * NCOLS;
+    const int iz0 = uz0 + g.emin[0], iy0 = uy0 + g.emin[1], ix0 = ux0 + g.emin[2];
+    const long in_rows_b = (long)b * g.In[0] * g.In[1] * g.In[2];
+    f32x4 acc[2][NCB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) acc[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // wave w owns row blocks 2w, 2w+1: (ry, rz) = (rb & 3, rb >> 2); this lane's box row before the tap offset
+    const unsigned char *abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int rb = 2 * wave + i; abase[i] = s_box + (((rb >> 2) * BY + (rb & 3)) * BX + r) * ROWB + (PREC ? 8 : 16) * q; }
+    const unsigned char *bbase = s_w + r * ROWB + (PREC ? 8 : 16) * q;
+
+    for (int ch0 = 0; ch0 < g.cin; ch0 += CH) {
+        __syncthreads();
+        // box: one (bz, by) row per wave and pass
+        for (int rowi = wave; rowi < BZ * BY; rowi += 8) {
+            const int bz = rowi / BY, by = rowi - bz * BY;
+            int iz = iz0 + bz, iy = iy0 + by;
+            bool okr = true;
+            if (g.mode == 0) { iz = min(max(iz, 0), g.In[0] - 1); iy = min(max(iy, 0), g.In[1] - 1); }
+            else { okr = iz >= 0 && iz < g.In[0] && iy >= 0 && iy < g.In[1]; if (!okr) { iz = 0; iy = 0; } }
+            const float *src_row = g.x + (in_rows_b + ((long)iz * g.In[1] + iy) * g.In[2]) * g.ldx + ch0;
+            unsigned char *dst_row = s_box + rowi * BX * ROWB;
+#pragma unroll
+            for (int it = 0; it < (BX * PER + 63) / 64; ++it) {
+                const int e = it * 64 + lane;
+                if (e < BX * PER) {
+                    const int bx = e >> PER_LOG, k4 = e & (PER - 1);
+                    int ix = ix0 + bx;
+                    bool ok = okr;
+                    if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
+                    else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
+                    f32x4 val = *(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4);
+                    if (!ok) val = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (PREC) {
+                        uint2 pk;
+                        pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
+                        *(uint2 *)(dst_row + bx * ROWB + 8 * k4) = pk;
+                    } else {
+                        *(f32x4 *)(dst_row + bx * ROWB + 16 * k4) = val;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int jz = 0; jz < 3; ++jz) {
+            if (jz) __syncthreads();
+            // the 9 weight tiles of this z-slice: wt[(jz * 3 + jy) * 3 + jx][col_w0 + c][ch0 ..]; one flat loop
+            {
+                const float *src = g.wt + ((long)(jz * 9) * g.cout + col_w0) * g.cin + ch0;
+                constexpr int TOTAL = 9 * NCOLS * PER;
+                for (int e = tid; e < TOTAL; e += 512) {
+                    const int tap = e / (NCOLS * PER), rem = e - tap * (NCOLS * PER);
+                    const int c = rem >> PER_LOG, k4 = rem & (PER - 1);
+                    const f32x4 v = *(const f32x4 *)(src + ((long)tap * g.cout + c) * g.cin + 4 * k4);
+                    if constexpr (PREC) {
+                        uint2 pk;
+                        pk.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); pk.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                        *(uint2 *)(s_w + tap * WTILE + c * ROWB + 8 * k4) = pk;
+                    } else {
+                        *(f32x4 *)(s_w + tap * WTILE + c * ROWB + 16 * k4) = v;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jy = 0; jy < 3; ++jy)
+#pragma unroll
+                for (int jx = 0; jx < 3; ++jx) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int boxoff = ((REV ? 2 - jz : jz) * BY + (REV ? 2 - jy : jy)) * BX + (REV ? 2 - jx : jx);
+                    const int wslot = jy * 3 + jx;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        if constexpr (PREC) {
+                            s16x4 a[2], bf[NCB];
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) a[i] = *(const s16x4 *)(abase[i] + boxoff * ROWB + 32 * k);
+#pragma unroll
+                            for (int c = 0; c < NCB; ++c) bf[c] = *(const s16x4 *)(bbase + wslot * WTILE + 16 * c * ROWB + 32 * k);
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int c = 0; c < NCB; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], bf[c], acc[i][c], 0, 0, 0);
+                        } else {
+                            f32x4 a[2], bf[NCB];
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) a[i] = *(const f32x4 *)(abase[i] + boxoff * ROWB + 64 * k);
+#pragma unroll
+                            for (int c = 0; c < NCB; ++c) bf[c] = *(const f32x4 *)(bbase + wslot * WTILE + 16 * c * ROWB + 64 * k);
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                    for (int c = 0; c < NCB; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][tt], bf[c][tt], acc[i][c], 0, 0, 0);
+                        }
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rb = 2 * wave + i;
+        const int uz = uz0 + (rb >> 2), uy = uy0 + (rb & 3);
+        if (uz >= g.Sub[0] || uy >= g.Sub[1]) continue;
+        const long rowz = (long)b * g.Out[0] * g.Out[1] * g.Out[2] + ((long)(g.p[0] + uz) * g.Out[1] + (g.p[1] + uy)) * g.Out[2] + g.p[2];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int col = col_w0 + 16 * c + r;
+            const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ux = ux0 + 4 * q + k;
+                if (ux < g.Sub[2]) g.y[(rowz + ux) * g.ldy + col] = acc[i][c][k] + bv;
+            }
+        }
+    }
+}
+
 // y[out row of sub-grid row][col] = bias + slab[0] + slab[1] + ... (fixed order)
 __global__ void k_dense_splitk_reduce(DenseArgs g, int Z)
 {
@@ -371,6 +518,44 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
         (void)hipFuncSetAttribute((const void *)k_dense_conv<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_dense_conv<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
+    }
+    // fast path: full 3 x 3 x 3 taps, unit strides, forward order (e = j + emin) or reversed (e = -j), 16 row blocks of
+    // 4 x 4, no split, a channel chunk whose box + 9 weight tiles fit
+    {
+        bool f3 = a.NRB == 16 && a.TY == 4 && a.TZ == 4 && !a.slab && ntaps == 27;
+        int rev = -1;
+        for (int d = 0; d < 3 && f3; ++d) {
+            f3 = a.nt[d] == 3 && a.s[d] == 1 && a.os[d] == 1 && a.kdim[d] == 3;
+            const bool fw = a.e[d][0] + 1 == a.e[d][1] && a.e[d][1] + 1 == a.e[d][2] && a.wi[d][0] == 0 && a.wi[d][1] == 1 && a.wi[d][2] == 2;
+            const bool rv = a.e[d][0] - 1 == a.e[d][1] && a.e[d][1] - 1 == a.e[d][2] && a.wi[d][0] == 0 && a.wi[d][1] == 1 && a.wi[d][2] == 2;
+            if (!fw && !rv) f3 = false;
+            const int rd = rv ? 1 : 0;
+            if (rev >= 0 && rev != rd) f3 = false;
+            rev = rd;
+        }
+        if (f3) {
+            int kc3 = 0, ncb = cout >= 64 ? 4 : cout / 16;
+            if (cout % (16 * ncb)) ncb = 1;
+            for (int k = 4; k >= 1 && !kc3; k >>= 1) {
+                if ((cin / 16) % k) continue;
+                const long rb3 = 16L * k * es + 16;
+                if (((648 * rb3 + 15) & ~15L) + 9L * 16 * ncb * rb3 <= 150 * 1024) kc3 = k;
+            }
+            if (kc3) {
+                const long rb3 = 16L * kc3 * es + 16;
+                const size_t lds3 = (size_t)(((648 * rb3 + 15) & ~15L) + 9L * 16 * ncb * rb3);
+                const dim3 grid3((unsigned)tiles, cout / (16 * ncb));
+                static bool attr3 = false;
+#define URN_D3(P, K, N, R) if (precision == P && kc3 == K && ncb == N && rev == R) { \
+                    if (!attr3) (void)hipFuncSetAttribute((const void *)k_dense_conv3<P, K, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    hipLaunchKernelGGL((k_dense_conv3<P, K, N, R>), grid3, dim3(512), lds3, st, a); URN_LAUNCH_CHECK(); return URN_OK; }
+#define URN_D3K(P, R) URN_D3(P, 1, 1, R) URN_D3(P, 1, 2, R) URN_D3(P, 1, 3, R) URN_D3(P, 1, 4, R) URN_D3(P, 2, 1, R) URN_D3(P, 2, 2, R) URN_D3(P, 2, 3, R) URN_D3(P, 2, 4, R) \
+                    URN_D3(P, 4, 1, R) URN_D3(P, 4, 2, R) URN_D3(P, 4, 3, R) URN_D3(P, 4, 4, R)
+                URN_D3K(0, 0) URN_D3K(0, 1) URN_D3K(1, 0) URN_D3K(1, 1)
+#undef URN_D3K
+#undef URN_D3
+            }
+        }
     }
     if (precision) hipLaunchKernelGGL(k_dense_conv<1>, grid, block, lds, st, a);
     else hipLaunchKernelGGL(k_dense_conv<0>, grid, block, lds, st, a);
@@ -584,6 +769,161 @@ __global__ __launch_bounds__(512) void k_dense_dw(DenseDwArgs g)
     }
 }
 
+// ---- fast path of the weight gradient: 3 x 3 x 3 taps, unit strides, tile 16 x 4 x 4 (box 18 x 6 x 6) -----------------------
+// Compile-time LDS offsets (see k_dense_conv3), the dy fragments of a row block loaded once for the wave's 3-4 taps, and for
+// bf16 the voxel-major tiles are read with ds_read_b64_tr_b16: one transposing read delivers, to lane (channel r, voxel
+// group q), the four voxels 4q..4q+3 of channel r -- the MFMA's k-contiguous operand -- where the generic kernel issues four
+// ds_read_u16 (it was LDS-instruction bound: 8 reads per MFMA at 16 channels).
+template <int PREC, int NCI, int NCO>
+__global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int ES = PREC ? 2 : 4, ROWB = 32 * ES + 16;
+    constexpr int BX = 18, BY = 6, BZ = 6, NBOX = BX * BY * BZ;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int n_ci = (g.cin + 31) / 32;
+    const int cic = blockIdx.y % n_ci, coc = blockIdx.y / n_ci;
+    const int ci0 = cic * 32, co0 = coc * 32;
+    unsigned char *s_box = smem_raw;
+    unsigned char *s_dy = smem_raw + ((NBOX * ROWB + 15) & ~15);
+    const int tiles_x = (g.Out[2] + 15) / 16, tiles_y = (g.Out[1] + 3) / 4, tiles_z = (g.Out[0] + 3) / 4;
+    const long ntiles = (long)tiles_x * tiles_y * tiles_z * g.B;
+    const long t_lo = ntiles * blockIdx.x / g.S, t_hi = ntiles * (blockIdx.x + 1) / g.S;
+    f32x4 acc[4][NCI][NCO];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < NCI; ++i)
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) acc[a][i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this wave's taps: wave + 8a; their box offsets (dz * BY + dy) * BX + dx
+    int toff[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { const int tap = min(wave + 8 * a, 26); toff[a] = ((tap / 9) * BY + (tap / 3) % 3) * BX + tap % 3; }
+    // per-lane byte offsets inside a row block: transposing read (bf16): lane i of a 16-lane group supplies row 4q + (i >> 2),
+    // columns 4 (i & 3); plain reads (fp32): voxel 4m + q, channel r
+    const int tr_row = 4 * q + (r >> 2), tr_col = 4 * (r & 3);
+
+    for (long tile = t_lo; tile < t_hi; ++tile) {
+        long t = tile;
+        const int tx = (int)(t % tiles_x); t /= tiles_x;
+        const int ty = (int)(t % tiles_y); t /= tiles_y;
+        const int tz = (int)(t % tiles_z); const int b = (int)(t / tiles_z);
+        const int ox0 = tx * 16, oy0 = ty * 4, oz0 = tz * 4;
+        const int iz0 = oz0 - g.lo[0], iy0 = oy0 - g.lo[1], ix0 = ox0 - g.lo[2];
+        __syncthreads();
+        for (int rowi = wave; rowi < BZ * BY; rowi += 8) {
+            const int bz = rowi / BY, by = rowi - bz * BY;
+            int iz = iz0 + bz, iy = iy0 + by;
+            bool okr = true;
+            if (g.mode == 0) { iz = min(max(iz, 0), g.In[0] - 1); iy = min(max(iy, 0), g.In[1] - 1); }
+            else { okr = iz >= 0 && iz < g.In[0] && iy >= 0 && iy < g.In[1]; if (!okr) { iz = 0; iy = 0; } }
+            const float *src_row = g.x + ((((long)b * g.In[0] + iz) * g.In[1] + iy) * g.In[2]) * g.ldx + ci0;
+            unsigned char *dst_row = s_box + rowi * BX * ROWB;
+#pragma unroll
+            for (int it = 0; it < (BX * 8 + 63) / 64; ++it) {
+                const int e = it * 64 + lane;
+                if (e < BX * 8) {
+                    const int bx = e >> 3, k4 = e & 7;
+                    int ix = ix0 + bx;
+                    bool ok = okr && 4 * k4 < 16 * NCI;
+                    if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
+                    else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
+                    f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (ok) val = *(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4);
+                    if constexpr (PREC) {
+                        uint2 pk;
+                        pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
+                        *(uint2 *)(dst_row + bx * ROWB + 8 * k4) = pk;
+                    } else {
+                        *(f32x4 *)(dst_row + bx * ROWB + 16 * k4) = val;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rb = wave + 8 * it;
+            const int oz = oz0 + (rb >> 2), oy = oy0 + (rb & 3);
+            const bool okr = oz < g.Out[0] && oy < g.Out[1];
+            const float *src_row = g.dy + ((((long)b * g.Out[0] + (okr ? oz : 0)) * g.Out[1] + (okr ? oy : 0)) * g.Out[2]) * g.ld_dy + co0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = h * 64 + lane;
+                const int vx = e >> 3, k4 = e & 7;
+                const int ox = ox0 + vx;
+                const bool ok = okr && ox < g.Out[2] && 4 * k4 < 16 * NCO;
+                f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok) val = *(const f32x4 *)(src_row + (long)ox * g.ld_dy + 4 * k4);
+                unsigned char *dst = s_dy + (rb * 16 + vx) * ROWB;
+                if constexpr (PREC) {
+                    uint2 pk;
+                    pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
+                    *(uint2 *)(dst + 8 * k4) = pk;
+                } else {
+                    *(f32x4 *)(dst + 16 * k4) = val;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rb = 0; rb < 16; ++rb) {
+            const int rbase = ((rb >> 2) * BY + (rb & 3)) * BX;
+            if constexpr (PREC) {
+                s16x4 bf[NCO];
+#pragma unroll
+                for (int c = 0; c < NCO; ++c)
+                    bf[c] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(s_dy + (rb * 16 + tr_row) * ROWB + 2 * (16 * c + tr_col)));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a == 3 && wave + 24 >= 27) break;          // waves 3..7 have three taps
+                    s16x4 af[NCI];
+#pragma unroll
+                    for (int i = 0; i < NCI; ++i)
+                        af[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(s_box + (rbase + toff[a] + tr_row) * ROWB + 2 * (16 * i + tr_col)));
+#pragma unroll
+                    for (int i = 0; i < NCI; ++i)
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c) acc[a][i][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[i], bf[c], acc[a][i][c], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int vx = 4 * m + q;
+                    float bf[NCO];
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c) bf[c] = *(const float *)(s_dy + (rb * 16 + vx) * ROWB + 4 * (16 * c + r));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (a == 3 && wave + 24 >= 27) break;
+#pragma unroll
+                        for (int i = 0; i < NCI; ++i) {
+                            const float af = *(const float *)(s_box + (rbase + toff[a] + vx) * ROWB + 4 * (16 * i + r));
+#pragma unroll
+                            for (int c = 0; c < NCO; ++c) acc[a][i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[c], acc[a][i][c], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float *out = g.slab + (long)blockIdx.x * 27 * g.cin * g.cout;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int tap = wave + 8 * a;
+        if (tap >= 27) break;
+#pragma unroll
+        for (int i = 0; i < NCI; ++i)
+#pragma unroll
+            for (int c = 0; c < NCO; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    out[((long)tap * g.cin + ci0 + 16 * i + 4 * q + k) * g.cout + co0 + 16 * c + r] = acc[a][i][c][k];
+    }
+}
+
 __global__ void k_dense_dw_reduce(const float *__restrict__ slab, int S, long n, float *__restrict__ dw)
 {
     const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -653,8 +993,23 @@ extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *d
         attr_done = true;
     }
     const dim3 grid((unsigned)S, ((cin + 31) / 32) * ((cout + 31) / 32)), block(512);
-    if (precision) hipLaunchKernelGGL(k_dense_dw<1>, grid, block, lds, st, a);
-    else hipLaunchKernelGGL(k_dense_dw<0>, grid, block, lds, st, a);
+    bool done = false;
+    {   // fast path: every channel block of the launch is a full 32 (or the layer has exactly 16 channels on that side)
+        const int nci = cin >= 32 ? 2 : 1, nco = cout >= 32 ? 2 : 1;
+        const bool full = (cin % 32 == 0 || cin == 16) && (cout % 32 == 0 || cout == 16);
+        if (ntap == 27 && stride == 1 && a.NRB == 16 && a.TY == 4 && a.TZ == 4 && full) {
+            static bool attr3 = false;
+#define URN_DW3(P, I, C) if (precision == P && nci == I && nco == C) { \
+                if (!attr3) (void)hipFuncSetAttribute((const void *)k_dense_dw3<P, I, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                hipLaunchKernelGGL((k_dense_dw3<P, I, C>), grid, block, lds, st, a); done = true; }
+            URN_DW3(0, 1, 1) URN_DW3(0, 1, 2) URN_DW3(0, 2, 1) URN_DW3(0, 2, 2) URN_DW3(1, 1, 1) URN_DW3(1, 1, 2) URN_DW3(1, 2, 1) URN_DW3(1, 2, 2)
+#undef URN_DW3
+        }
+    }
+    if (!done) {
+        if (precision) hipLaunchKernelGGL(k_dense_dw<1>, grid, block, lds, st, a);
+        else hipLaunchKernelGGL(k_dense_dw<0>, grid, block, lds, st, a);
+    }
     hipLaunchKernelGGL(k_dense_dw_reduce, dim3(urn_cdiv((n + 3) / 4, 256)), dim3(256), 0, st, (const float *)scratch, (int)S, n, dw);
     URN_LAUNCH_CHECK();
     return URN_OK;
