@@ -283,7 +283,12 @@ __global__ __launch_bounds__(512) void k_dense_conv3(DenseArgs g)
     for (int i = 0; i < 2; ++i) { const int rb = 2 * wave + i; abase[i] = s_box + (((rb >> 2) * BY + (rb & 3)) * BX + r) * ROWB + (PREC ? 8 : 16) * q; }
     const unsigned char *bbase = s_w + r * ROWB + (PREC ? 8 : 16) * q;
 
-    for (int ch0 = 0; ch0 < g.cin; ch0 += CH) {
+    // split contraction (see k_dense_conv): blockIdx.z = chunk slice * zt + z-slice of the taps (zt = 1 or 3)
+    const int nchunks = g.cin / CH;
+    const int zci = blockIdx.z / g.zt, zti = blockIdx.z - zci * g.zt;
+    const int chunk_lo = nchunks * zci / g.zc, chunk_hi = nchunks * (zci + 1) / g.zc;
+    const int jz_lo = g.zt == 3 ? zti : 0, jz_hi = g.zt == 3 ? zti + 1 : 3;
+    for (int ch0 = chunk_lo * CH; ch0 < chunk_hi * CH; ch0 += CH) {
         __syncthreads();
         // box: one (bz, by) row per wave and pass
         for (int rowi = wave; rowi < BZ * BY; rowi += 8) {
@@ -317,7 +322,8 @@ __global__ __launch_bounds__(512) void k_dense_conv3(DenseArgs g)
         }
 #pragma unroll
         for (int jz = 0; jz < 3; ++jz) {
-            if (jz) __syncthreads();
+            if (jz < jz_lo || jz >= jz_hi) continue;       // workgroup-uniform
+            if (jz > jz_lo) __syncthreads();
             // the 9 weight tiles of this z-slice: wt[(jz * 3 + jy) * 3 + jx][col_w0 + c][ch0 ..]; one flat loop
             {
                 const float *src = g.wt + ((long)(jz * 9) * g.cout + col_w0) * g.cin + ch0;
@@ -372,20 +378,25 @@ __global__ __launch_bounds__(512) void k_dense_conv3(DenseArgs g)
                 }
         }
     }
+    const bool split = g.slab != nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rb = 2 * wave + i;
         const int uz = uz0 + (rb >> 2), uy = uy0 + (rb & 3);
         if (uz >= g.Sub[0] || uy >= g.Sub[1]) continue;
         const long rowz = (long)b * g.Out[0] * g.Out[1] * g.Out[2] + ((long)(g.p[0] + uz) * g.Out[1] + (g.p[1] + uy)) * g.Out[2] + g.p[2];
+        const long nsub = (long)g.B * g.Sub[0] * g.Sub[1] * g.Sub[2];
+        const long srow0 = (((long)b * g.Sub[0] + uz) * g.Sub[1] + uy) * g.Sub[2];
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
             const int col = col_w0 + 16 * c + r;
-            const float bv = g.bias ? g.bias[col] : 0.f;
+            const float bv = (g.bias && !split) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ux = ux0 + 4 * q + k;
-                if (ux < g.Sub[2]) g.y[(rowz + ux) * g.ldy + col] = acc[i][c][k] + bv;
+                if (ux >= g.Sub[2]) continue;
+                if (split) g.slab[((long)blockIdx.z * nsub + srow0 + ux) * g.cout + col] = acc[i][c][k];
+                else g.y[(rowz + ux) * g.ldy + col] = acc[i][c][k] + bv;
             }
         }
     }
@@ -472,7 +483,10 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
     a.NRB = strided ? 4 : 16; a.cw = 64;
     {
         int ty, tz;
-        if (a.NRB == 16 && tiles_for(16, ty, tz) * ((cout + 63) / 64) < 512) a.NRB = 4;
+        bool k333 = !strided;
+        for (int d = 0; d < 3; ++d) k333 = k333 && a.nt[d] == 3 && a.os[d] == 1 && a.Sub[d] >= 4;
+        // (the 3 x 3 x 3 fast path keeps its 256-output tile and splits the contraction instead; everything else shrinks the tile)
+        if (a.NRB == 16 && !k333 && tiles_for(16, ty, tz) * ((cout + 63) / 64) < 512) a.NRB = 4;
         (void)tiles_for(a.NRB, a.TY, a.TZ);
     }
     a.box[2] += a.s[2] * 15; a.box[1] += a.s[1] * (a.TY - 1); a.box[0] += a.s[0] * (a.TZ - 1);
@@ -522,7 +536,7 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
     // fast path: full 3 x 3 x 3 taps, unit strides, forward order (e = j + emin) or reversed (e = -j), 16 row blocks of
     // 4 x 4, no split, a channel chunk whose box + 9 weight tiles fit
     {
-        bool f3 = a.NRB == 16 && a.TY == 4 && a.TZ == 4 && !a.slab && ntaps == 27;
+        bool f3 = a.NRB == 16 && a.TY == 4 && a.TZ == 4 && ntaps == 27;
         int rev = -1;
         for (int d = 0; d < 3 && f3; ++d) {
             f3 = a.nt[d] == 3 && a.s[d] == 1 && a.os[d] == 1 && a.kdim[d] == 3;
@@ -544,11 +558,25 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
             if (kc3) {
                 const long rb3 = 16L * kc3 * es + 16;
                 const size_t lds3 = (size_t)(((648 * rb3 + 15) & ~15L) + 9L * 16 * ncb * rb3);
-                const dim3 grid3((unsigned)tiles, cout / (16 * ncb));
+                // split for the fast path: z-slices of the taps (3) x chunk slices
+                const int gy3 = cout / (16 * ncb), nch3 = cin / (16 * kc3);
+                a.zc = a.zt = 1;
+                if (tiles * gy3 < 384 && scratch) {
+                    long want = (1024 + tiles * gy3 - 1) / (tiles * gy3);
+                    a.zt = want >= 3 ? 3 : 1;
+                    want = (want + a.zt - 1) / a.zt;
+                    a.zc = (int)(want < nch3 ? want : nch3);
+                    if (a.zc < 1) a.zc = 1;
+                    if (scratch_bytes < (int64_t)a.zc * a.zt * nsub * cout * 4) a.zc = a.zt = 1;
+                }
+                a.slab = a.zc * a.zt > 1 ? (float *)scratch : nullptr;
+                const dim3 grid3((unsigned)tiles, gy3, a.zc * a.zt);
                 static bool attr3 = false;
 #define URN_D3(P, K, N, R) if (precision == P && kc3 == K && ncb == N && rev == R) { \
                     if (!attr3) (void)hipFuncSetAttribute((const void *)k_dense_conv3<P, K, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                    hipLaunchKernelGGL((k_dense_conv3<P, K, N, R>), grid3, dim3(512), lds3, st, a); URN_LAUNCH_CHECK(); return URN_OK; }
+                    hipLaunchKernelGGL((k_dense_conv3<P, K, N, R>), grid3, dim3(512), lds3, st, a); \
+                    if (a.slab) hipLaunchKernelGGL(k_dense_splitk_reduce, dim3(urn_cdiv(nsub * (cout / 4), 256)), dim3(256), 0, st, a, a.zc * a.zt); \
+                    URN_LAUNCH_CHECK(); return URN_OK; }
 #define URN_D3K(P, R) URN_D3(P, 1, 1, R) URN_D3(P, 1, 2, R) URN_D3(P, 1, 3, R) URN_D3(P, 1, 4, R) URN_D3(P, 2, 1, R) URN_D3(P, 2, 2, R) URN_D3(P, 2, 3, R) URN_D3(P, 2, 4, R) \
                     URN_D3(P, 4, 1, R) URN_D3(P, 4, 2, R) URN_D3(P, 4, 3, R) URN_D3(P, 4, 4, R)
                 URN_D3K(0, 0) URN_D3K(0, 1) URN_D3K(1, 0) URN_D3K(1, 1)
