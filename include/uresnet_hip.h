@@ -386,15 +386,19 @@ int urn_prof_enable(int on);
  *   "gconv_precision" 0 fp32 (default) | 1 bf16 | 2 fp16 -- MFMA operand precision of calls that do not set
  *                     urn_gconv_args.precision, and of the weight gradient.
  * Tuning / A-B switches (defaults are the measured optima; tools/ use them):
- *   "gconv_kernel" 6 2-D tile (default) | 4 64x16 LDS tile | 5 LDS-DMA ring | 3 register gather;
- *   "tile_il" 1/0 interleaved offset step, "tile_il_min_ks" narrowest channel step that takes it;
- *   "tile_rb" / "tile_cb" / "tile_kc" force the workgroup tile / channels per step (0 = automatic);
+ *   "gconv_kernel" 7 pair-list kernel for calls that carry a list, 2-D tile otherwise (default) | 6 2-D tile | 3 register
+ *                  gather; "pairs_max_cin" / "pairs_max_cout" / "pairs_nin" which shapes take the pair-list kernel;
+ *   "pairs_nc" / "pairs_split" / "pairs_cbg" / "pairs_wgs" / "pairs_waves" its column blocks per wave, split of a tile's
+ *   block list, column groups per workgroup and the workgroup / wave targets (0 = automatic);
+ *   "dw_pairs" 1 = weight gradients on the two-stage pair-list kernel (bitwise reproducible; default 0 = dense-table kernel
+ *   with fp32 atomics), "dwp_waves" / "dwp_smax" / "dwp_cap" its wave target, share limit and register block;
+ *   "tile_il" 1/0 interleaved offset step of the 2-D tile kernel, "tile_il_min_ks" narrowest channel step that takes it,
+ *   "tile_rb" / "tile_cb" / "tile_kc" force its workgroup tile / channels per step (0 = automatic);
  *   "dw_kernel" 2/1, "dw_blocks" workgroup target, "dw_split" 0 never | 1 automatic | 2 always, "dw_group"
- *   weight gradients per fork to the side stream; "net_side_probe" candidate side streams an executor's first
- *   backward times against the caller's stream (default 4; 0 keeps the first), "net_side_verbose" 1 prints the
- *   probe times to stderr; "fin_in_kernel" finalize BatchNorm statistics by the last
- *   workgroup (slab mode); "gconv_dbg" timing-only ablation / probe mask (results are garbage with most bits);
- *   "gconv_pipe", "gconv_min_waves", "gconv_lds_min_wgs" knobs of the older kernels. */
+ *   weight gradients per fork to the side stream; "net_side_probe" candidate side streams urn_net_probe times against the
+ *   caller's stream (default 4; 0 keeps the first), "net_side_verbose" 1 prints the probe times to stderr;
+ *   "gconv_dbg" timing-only ablation / probe mask of the 2-D tile kernel (results are garbage with most bits);
+ *   "gconv_pipe", "gconv_min_waves" knobs of the register-gather fallback. */
 int urn_set_option(const char *key, int64_t value);
 int urn_prof_read(int kind, double *total_ms, int64_t *launches);
 

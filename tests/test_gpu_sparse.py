@@ -708,6 +708,47 @@ def test_network_cfg5_size_modes_agree(dev):
     assert rel(res[0][2], res[1][2]) < 1e-3      # ReLU-mask flips between the two summation orders (see cfg3 test)
 
 
+def test_network_cfg5_fp16_full_size_with_loss_scaling(dev):
+    """BASELINE configs[4] at FULL size in fp16: -ss 768, 200k voxels, -uf 32 -uns 7, MFMA operands rounded to fp16 (fp32
+    tensors and accumulation).  Too large for the oracle in seconds, so the fp32 run of the same executor is the
+    reference (itself pinned to the oracle at cfg3 / cfg4 size above):
+      * everything finite; logits within the fp16 operator tolerance of the fp32 run (8e-3 norm-wise, the bound of
+        test_reduced_precision_operands for the small network);
+      * gradients: WITHOUT loss scaling the gradient operands (1e-6 .. 1e-8 here) fall below fp16's range when they are
+        rounded for the matrix cores; with the trainer's loss scale (flags -ls, 2^12) the norm-wise deviation of all
+        parameter gradients from the fp32 run is bounded by 0.02 (measured 0.004; 0.023 without the scale)."""
+    from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
+    S, m, Lv, nc = 768, 32, 7, 5
+    blob = make_sparse_blob([5], S, 200000)
+    data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
+
+    def run(prec, scale):
+        flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=nc, PRECISION=prec)
+        torch.manual_seed(0)
+        net = SparseUResNet(flags).to(dev).train()
+        out = net(data)
+        loss, acc = SparseSegmentationLoss(flags)(out, [data], [label], None)
+        (loss * scale).backward()
+        g = torch.cat([p.grad.reshape(-1) for p in net.parameters()]) / scale
+        return out[0].detach().cpu().numpy(), float(loss.detach()), g.cpu().numpy()
+    try:
+        lo32, l32, g32 = run('fp32', 1.0)
+        lo16, l16, g16 = run('fp16', 1.0)
+        lo16s, l16s, g16s = run('fp16', 4096.0)
+    finally:
+        from uresnet_pytorch_amd import lib as L_
+        L_.set_precision('fp32')
+    for a in (lo16, g16, lo16s, g16s):
+        assert np.isfinite(a).all()
+    e_logits = rel(lo16, lo32)
+    assert 1e-6 < e_logits < 8e-3, e_logits                     # > 1e-6: the fp16 kernels really ran
+    assert abs(l16 - l32) < 8e-3 * abs(l32)
+    e_plain, e_scaled = rel(g16, g32), rel(g16s, g32)
+    print('cfg5 fp16 full size: logits %.2e, gradients %.3f unscaled / %.3f with loss scale 2^12' % (e_logits, e_plain, e_scaled))
+    assert e_scaled < 0.02, (e_plain, e_scaled)                 # measured 0.004 (0.023 without the loss scale)
+    assert e_scaled <= e_plain * 1.05, (e_plain, e_scaled)
+
+
 def test_executor_eval_mode_matches_per_layer_path(dev):
     """Inference (model.eval(), no autograd: trainval.forward with TRAIN=False) through the executor -- BatchNorm folded
     into the convolutions with the RUNNING statistics -- against the per-layer eval path."""

@@ -256,7 +256,7 @@ int g_opt_precision = 0;   // default MFMA operand precision of the gather convo
 extern int g_dw_pairs;
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
-static int g_opt_fin_in_kernel = 0;
+static const int g_opt_fin_in_kernel = 0;   // (the in-kernel finalize lived in the removed 64x16 LDS kernel)
 static int g_opt_pipe = 0;
 static int g_opt_kernel = 7;   // 7 = compacted rule lists when the call carries them (urn_gconv_pairs.hip), else the 2-D tile; 6 = 2-D workgroup tile (urn_gconv_tile.hip); 3 = register gather (fallback for shapes without a tile instantiation)
 extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs, g_dwp_waves, g_dwp_smax, g_dwp_dbg, g_dwp_cap;
@@ -300,7 +300,6 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "net_side_verbose")) { g_net_side_verbose = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_group")) { g_dw_group = value > 0 ? (int)value : 1; return URN_OK; }
     if (!strcmp(key, "dw_blocks")) { g_dw_blocks = value > 0 ? (int)value : 1152; return URN_OK; }
-    if (!strcmp(key, "fin_in_kernel")) { g_opt_fin_in_kernel = value != 0; return URN_OK; }
     urn_set_error("urn_set_option: unknown key %s", key);
     return URN_EINVAL;
 }

@@ -5,8 +5,9 @@ conv_bn_act: replicate-pad (asymmetric) -> conv k{1,3} s{1,2} -> BatchNorm with 
 residual add -> optional ReLU.  convT_bn_act: ConvTranspose k3 s2 p1 op1 -> BN -> ReLU.
 
 CPU tensors run on torch/ATen (BASELINE configs[0], the reference's own CPU-runnable case).
-GPU tensors are routed to the dense HIP kernels when they are built (urn_dense_*); until then
-the GPU route raises, because the product path has no silent fallback.
+GPU tensors run on the dense HIP kernels (dense_hip.py -> dense_conv.py -> csrc/urn_dense.hip: implicit-GEMM
+convolutions with the replicate clamp in the addressing, fp32 or bf16 MFMA operands) and the BatchNorm row
+kernels; a missing library raises, there is no silent fallback.
 """
 import torch
 import torch.nn.functional as F

@@ -41,6 +41,7 @@ class URESNET_FLAGS:
     WEIGHT_PREFIX = ''
     NUM_POINT = 2048
     PRECISION = 'fp32'
+    LOSS_SCALE = 1.0
     NUM_CHANNEL = -1
     ITERATION = 10000
     REPORT_STEP = 100
@@ -93,6 +94,9 @@ class URESNET_FLAGS:
         a('-np', '--num_point', type=int, default=self.NUM_POINT, help='Active voxels per synthetic event')
         a('-prec', '--precision', type=str, default=self.PRECISION, choices=['fp32', 'bf16', 'fp16'],
           help='MFMA operand precision of the convolutions on the GPU (tensors and accumulation stay fp32)')
+        a('-ls', '--loss_scale', type=float, default=self.LOSS_SCALE,
+          help='loss scale of a training step (a power of two; gradients are unscaled before the optimizer): keeps the '
+               'gradient operands of -prec fp16 inside its exponent range')
         return parser
 
     def _build_parsers(self):

@@ -37,7 +37,15 @@ class trainval(object):
         total_loss = total_loss / len(self._loss)
         self._loss = []
         self._grads.zero()
+        # loss scaling (flags -ls, a power of two): the backward pass is linear in the incoming gradient, so scaling the
+        # loss scales every gradient operand -- with -prec fp16 the unscaled ones (1e-6 .. 1e-8 at cfg5 size) fall below
+        # fp16's range when they are rounded for the matrix cores; the flat gradient buffer is unscaled in one pass
+        scale = float(getattr(self._flags, 'LOSS_SCALE', 1.0) or 1.0)
+        if scale != 1.0:
+            total_loss = total_loss * scale
         total_loss.backward()
+        if scale != 1.0:
+            self._grads.flat.mul_(1.0 / scale)
         # SUM over ranks (the reference loss is a sum over all events): ONE collective over the flat buffer, started
         # asynchronously behind the backward kernels (RCCL waits for the stream's event on its own stream) and joined
         # right before the optimizer reads the gradients
