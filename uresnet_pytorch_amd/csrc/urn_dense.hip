@@ -974,7 +974,7 @@ extern "C" int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, co
     if (!out_dims || !k || cin <= 0 || cout <= 0) return -1;
     const long ntap = (long)k[0] * k[1] * k[2];
     const long tiles = (long)((out_dims[2] + 15) / 16) * out_dims[1] * out_dims[0] * batch;   // upper bound on the tile count
-    long S = tiles < 256 ? tiles : 256;
+    long S = tiles < 512 ? tiles : 512;   // two workgroups per CU (72 KB of LDS each): one stages while the other multiplies
     if (S < 1) S = 1;
     return S * ntap * cin * cout * 4 + 256;
 }
@@ -1008,7 +1008,7 @@ extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *d
     const size_t lds = (size_t)(((nbox * rowb + 15) & ~15L) + (long)a.NRB * 16 * rowb);
     if (lds > 160 * 1024) { urn_set_error("urn_dense_dw: staged box of %ld voxels does not fit LDS", nbox); return URN_EUNSUPPORTED; }
     const long ntiles = (long)((a.Out[2] + 15) / 16) * ((a.Out[1] + a.TY - 1) / a.TY) * ((a.Out[0] + a.TZ - 1) / a.TZ) * batch;
-    long S = ntiles < 256 ? ntiles : 256;
+    long S = ntiles < 512 ? ntiles : 512;
     if (S < 1) S = 1;
     const long n = (long)ntap * cin * cout;
     URN_CHECK_ARG(scratch_bytes >= S * n * 4, "scratch smaller than urn_dense_dw_scratch_bytes");
