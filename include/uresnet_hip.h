@@ -316,20 +316,51 @@ typedef struct {
 /* scratch (urn_dense_conv_scratch_bytes, may be NULL): launches with few output tiles (the deep levels: 4^3 voxels x 512
  * channels) split the contraction over workgroups into partial outputs there and sum them in a fixed order. */
 int64_t urn_dense_conv_scratch_bytes(int cout, int batch, const urn_dense_geom *geom);
+/* stats (may be NULL): a zeroed [stat_slots][2][cout] fp64 slab; the call ADDS the column sums and sums of squares of the
+ * outputs it writes (fp64 atomics from the epilogue, workgroup % stat_slots picks the row) -- the batch statistics of the
+ * BatchNorm that follows every convolution of the model without a pass over y; several calls (the parity classes of a
+ * transposed conv) accumulate into one slab; urn_bn_finalize_fwd(stats, stat_slots, ...) turns it into mean / invstd /
+ * scale / shift.  Needs 256 % (cout / 4) == 0. */
 int urn_dense_conv(const float *x, int64_t ldx, int cin, const float *wt, const float *bias, float *y, int64_t ldy, int cout,
-                   int batch, const urn_dense_geom *geom, int precision, void *scratch, int64_t scratch_bytes, void *stream);
+                   int batch, const urn_dense_geom *geom, int precision, double *stats, int stat_slots, void *scratch,
+                   int64_t scratch_bytes, void *stream);
 /* Gradient of F.pad(mode='replicate') (reference uresnet_dense.py:75-80): dx[i] = sum of dxp over the padded positions
  * that clamp to voxel i.  dxp: rows of the padded volume (dims + pad_lo + pad_hi), dx: rows of the volume; c % 4 == 0. */
 /* Weight gradient of the same convolutions: dw[tap][ci][co] (+)= sum over outputs o of x[in(o, tap)][ci] * dy[o][co] with
  * in = s * o + tap - lo, clamped (mode 0: the replicate-padded conv) or skipped when out of range (mode 1: the transposed
  * conv, called with the roles of input and output swapped).  in_dims / out_dims / k / s / lo in z, y, x order.  Two stages,
- * no atomics: per-share partial sums in `scratch` (urn_dense_dw_scratch_bytes), then dw += the shares in a fixed order. */
+ * no atomics: per-share partial sums in `scratch` (urn_dense_dw_scratch_bytes), then the shares are summed in a fixed
+ * order: dw_layout 0 ADDS them to dw[tap][cin][cout]; dw_layout 1 WRITES torch's parameter layout
+ * dw[(co * cin_valid + ci) * taps + tap] for ci < cin_valid, co < cout_valid (the zero-padded channels dropped): the
+ * .grad of nn.Conv's (cout, cin, *k) weight -- and of nn.ConvTranspose's (cin, cout, *k) when the call has the roles swapped. */
 int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, const int *k, int cin, int cout);
 int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *dy, int64_t ld_dy, int cout, int batch, const int *in_dims,
-                 const int *out_dims, const int *k, const int *s, const int *lo, int mode, float *dw, void *scratch,
-                 int64_t scratch_bytes, int precision, void *stream);
+                 const int *out_dims, const int *k, const int *s, const int *lo, int mode, float *dw, int dw_layout, int cin_valid,
+                 int cout_valid, void *scratch, int64_t scratch_bytes, int precision, void *stream);
 int urn_dense_fold(const float *dxp, float *dx, int batch, const int *dims, const int *pad_lo, const int *pad_hi, int c,
                    void *stream);
+/* Row passes around the convolutions (reference uresnet_dense.py:72-83: conv -> BatchNorm(batch statistics) [-> + shortcut]
+ * [-> ReLU]); (n, c) fp32 row matrices, c % 4 == 0 and 256 % (c / 4) == 0.
+ * urn_dense_bn_act_fwd:  out = [relu](raw * scale + shift [+ res | + res * res_scale + res_shift]) in ONE pass; res NULL =
+ *   no shortcut, res_scale NULL = identity shortcut, else res is the raw output of the shortcut conv with its own folded
+ *   BatchNorm.  scale / shift come from urn_bn_finalize_fwd on the statistics slab of urn_dense_conv.
+ * urn_dense_bn_act_bwd_reduce: with g = d_out * [out > 0] (out NULL = no ReLU), ADDS (sum g, sum g * xhat) per channel into
+ *   the zeroed [slots][2][c] fp64 slab `sums` (xhat = (raw - mean) * invstd) and, with res_raw, the same for the shortcut
+ *   BatchNorm into `res_sums`; urn_bn_finalize_bwd(sums, slots, ...) gives dgamma / dbeta and the two coefficients.
+ * urn_dense_bn_act_bwd_apply: d_raw = gamma * invstd * (g - coef0 - xhat * coef1); d_res (may be NULL) = the same for the
+ *   shortcut BatchNorm when res_raw is given, else g itself (the gradient of an identity shortcut). */
+int urn_dense_bn_act_fwd(const float *raw, const float *scale, const float *shift, const float *res, const float *res_scale,
+                         const float *res_shift, int relu, float *out, int64_t n, int c, void *stream);
+int urn_dense_bn_act_bwd_reduce(const float *d_out, const float *out, const float *raw, const float *mean, const float *invstd,
+                                const float *res_raw, const float *res_mean, const float *res_invstd, int64_t n, int c,
+                                double *sums, double *res_sums, int slots, void *stream);
+/* (sum g, sum g * xhat) slabs -> dgamma, dbeta (WRITTEN) and coef0 = sum g / n, coef1 = sum g * xhat / n; nb = 1 or 2
+ * BatchNorms in one launch: slab b at sums + b * slots * 2 * c, outputs as rows of out[nb][4][c] = dgamma, dbeta, coef0, coef1 */
+int urn_dense_bn_bwd_finalize(const double *sums, int nb, int slots, int64_t n, int c, float *out, void *stream);
+int urn_dense_bn_act_bwd_apply(const float *d_out, const float *out, const float *raw, const float *gamma, const float *mean,
+                               const float *invstd, const float *coef0, const float *coef1, const float *res_raw,
+                               const float *res_gamma, const float *res_mean, const float *res_invstd, const float *res_coef0,
+                               const float *res_coef1, float *d_raw, float *d_res, int64_t n, int c, void *stream);
 
 /* ------------------------------------------------------------------ whole-network executor
  * The trunk of the sparse model -- everything between scn.InputLayer and torch.nn.Linear at

@@ -102,3 +102,83 @@ def test_dense_conv_transpose_forward_backward(dev, dim, spatial, cin, cout, pre
         assert rel(bg.grad, br.grad) < 1e-5
     finally:
         dc.set_precision('fp32')
+
+
+# ---- statistics in the convolution epilogue, fused BatchNorm + shortcut + ReLU row passes ---------------------------------
+STAT_CASES = [  # dim, spatial, cin, cout, k, stride  (unsplit fast path, generic kernel, strided, split contraction, padded channels)
+    (3, (16, 16, 16), 16, 16, 3, 1), (3, (8, 12, 16), 16, 32, 3, 2), (3, (8, 8, 8), 32, 64, 1, 2), (3, (4, 4, 4), 64, 128, 3, 1),
+    (2, (20, 12), 8, 32, 3, 2), (2, (9, 17), 1, 8, 3, 1), (3, (8, 8, 8), 128, 256, 3, 1),
+]
+
+
+@pytest.mark.parametrize('dim,spatial,cin,cout,k,stride', STAT_CASES)
+def test_dense_conv_epilogue_statistics(dev, dim, spatial, cin, cout, k, stride):
+    """the [slots][2][cout] slab the epilogue fills = column sums / sums of squares of the output it wrote"""
+    from uresnet_pytorch_amd import dense_conv as dc
+    B = 2
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    x = torch.randn(B, cin, *spatial, generator=g)
+    w = torch.randn(cout, cin, *([k] * dim), generator=g) / (cin * k ** dim) ** 0.5
+    b = torch.randn(cout, generator=g)
+    lo, hi = ref_padding(k, stride, spatial[-1])
+    stats = dc.new_stats(cout + (-cout) % 16, dev)
+    y = dc.DenseConvFunction.apply(to_rows(x).to(dev), w.to(dev), b.to(dev), B, spatial, stride, lo, hi, stats, False)
+    s = stats.sum(0).cpu()
+    yd = y.double().cpu()
+    assert float((s[0, :cout] - yd.sum(0)).abs().max()) <= 1e-9 * float(yd.abs().sum(0).max())
+    assert float((s[1, :cout] - (yd * yd).sum(0)).abs().max()) <= 1e-9 * float((yd * yd).sum(0).max())
+    assert float(s[:, cout:].abs().max()) == 0.0 if s.shape[1] > cout else True
+
+
+def test_dense_conv_transpose_epilogue_statistics(dev):
+    from uresnet_pytorch_amd import dense_conv as dc
+    B, cin, cout, spatial = 2, 32, 16, (4, 6, 8)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, *spatial, generator=g)
+    w = torch.randn(cin, cout, 3, 3, 3, generator=g) / 30.
+    stats = dc.new_stats(cout, dev)
+    y = dc.DenseConvTransposeFunction.apply(to_rows(x).to(dev), w.to(dev), None, B, spatial, stats, False)
+    s = stats.sum(0).cpu()
+    yd = y.double().cpu()
+    assert float((s[0] - yd.sum(0)).abs().max()) <= 1e-9 * float(yd.abs().sum(0).max())
+    assert float((s[1] - (yd * yd).sum(0)).abs().max()) <= 1e-9 * float((yd * yd).sum(0).max())
+
+
+@pytest.mark.parametrize('c,n', [(16, 5000), (4, 777), (64, 1031), (512, 96)])
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('res', ['none', 'identity', 'bn'])
+def test_dense_bn_act_function_matches_torch(dev, c, n, relu, res):
+    """BNActFunction (statistics slab in, one forward pass, reduce + apply backward) against the torch composite
+    batch_norm(raw) [+ r | + batch_norm(r)] [-> relu] in fp64: forward 1e-6, every gradient 1e-5 (norm-wise)"""
+    from uresnet_pytorch_amd import dense_hip as dh
+    g = torch.Generator().manual_seed(c + n)
+    raw = torch.randn(n, c, generator=g) * 2 + 0.5
+    r = torch.randn(n, c, generator=g)
+    ga, be, rga, rbe = (torch.randn(c, generator=g) for _ in range(4))
+    dy = torch.randn(n, c, generator=g)
+    eps = 1e-5
+
+    def slab(t):
+        s = torch.zeros(8, 2, c, dtype=torch.float64)
+        td = t.double()
+        s[3, 0] = td.sum(0); s[5, 1] = (td * td).sum(0)          # any split over the slots must do
+        return s.to(dev)
+    # torch fp64 reference
+    P = [t.double().clone().requires_grad_(True) for t in (raw, ga, be, r, rga, rbe)]
+    y = F.batch_norm(P[0], None, None, P[1], P[2], True, 0.0, eps)
+    if res == 'identity':
+        y = y + P[3]
+    elif res == 'bn':
+        y = y + F.batch_norm(P[3], None, None, P[4], P[5], True, 0.0, eps)
+    if relu:
+        y = F.relu(y)
+    y.backward(dy.double())
+    Q = [t.to(dev).requires_grad_(True) for t in (raw, ga, be, r, rga, rbe)]
+    out = dh.BNActFunction.apply(Q[0], Q[1], Q[2], slab(raw), eps, relu, None if res == 'none' else Q[3],
+                                 Q[4] if res == 'bn' else None, Q[5] if res == 'bn' else None, slab(r) if res == 'bn' else None, eps)
+    out.backward(dy.to(dev))
+    assert rel(out, y) < 1e-6
+    names = ['raw', 'gamma', 'beta', 'res', 'res_gamma', 'res_beta']
+    used = {'none': 3, 'identity': 4, 'bn': 6}[res]
+    for i in range(used):
+        assert rel(Q[i].grad, P[i].grad) < 1e-5, names[i]

@@ -24,6 +24,6 @@ for S, c in [(128, 16), (64, 32), (32, 64), (16, 128), (8, 256), (64, 16), (128,
     for prec in ('fp32', 'bf16'):
         dc.set_precision(prec)
         t = timeit(lambda: dc._launch(x, c, c, wt, None, y, c, c, 1, fwd))
-        tw = timeit(lambda: dc._dw_call(x, c, dy, c, 1, [S, S, S], [S, S, S], [3, 3, 3], [1, 1, 1], [1, 1, 1], 0))
+        tw = timeit(lambda: dc._dw_call(x, c, dy, c, 1, [S, S, S], [S, S, S], [3, 3, 3], [1, 1, 1], [1, 1, 1], 0, c, c, (c, c, 3, 3, 3)))
         out.append('%s fwd %.0f us (%.0f TF/s) dW %.0f us (%.0f TF/s)' % (prec, t, fl / t / 1e6, tw, fl / tw / 1e6))
     print('%3d^3 %3d->%3d  %s' % (S, c, c, ' | '.join(out)), flush=True)

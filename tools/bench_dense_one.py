@@ -12,5 +12,5 @@ Out, fwd, bwd, _ = dc.conv_geoms((S, S, S), 3, 1, 1, 1)
 dc.set_precision(prec)
 for _ in range(4):
     dc._launch(x, c, c, wt, None, y, c, c, 1, fwd)
-    dc._dw_call(x, c, dy, c, 1, [S, S, S], [S, S, S], [3, 3, 3], [1, 1, 1], [1, 1, 1], 0)
+    dc._dw_call(x, c, dy, c, 1, [S, S, S], [S, S, S], [3, 3, 3], [1, 1, 1], [1, 1, 1], 0, c, c, (c, c, 3, 3, 3))
 torch.cuda.synchronize()

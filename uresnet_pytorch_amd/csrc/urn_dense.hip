@@ -46,7 +46,38 @@ struct DenseArgs {
     float *slab;                                    // split > 1: partial outputs [z][sub-grid row][cout] instead of y
     int ntaps;
     int tap_w[27], tap_box[27];                     // per tap: weight tap index, offset of the tap inside the staged box (voxels)
+    double *stats;                                  // optional [stat_slots][2][cout]: column sums / sums of squares of y ADDED (fp64 atomics)
+    int stat_slots;
 };
+
+// Column statistics of the outputs a workgroup has just computed (the BatchNorm that follows every convolution of the dense
+// model, reference uresnet_dense.py:45,57,68: batch statistics): lane (r, q) hands in, per column block, the sums over ITS
+// rows; the lanes of a wave are combined with shuffles, the waves through LDS (free after the last MFMA), the workgroup
+// adds 2 * ncols doubles into slot (workgroup % slots) of the slab.
+template <int MAXCB>
+__device__ __forceinline__ void dense_stats_flush(double (&d0)[MAXCB], double (&d1)[MAXCB], int cb_lo, int cb_hi, int ncols, int col_w0,
+                                                  int cout, double *stats, int slots, unsigned wg, unsigned char *smem_raw)
+{
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4, nthreads = blockDim.x;
+    double *s_red = (double *)smem_raw;
+    __syncthreads();                                       // every wave is done with the staged box / weight tiles
+    for (int e = tid; e < 2 * ncols; e += nthreads) s_red[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < MAXCB; ++c) {
+        if (c < cb_lo || c >= cb_hi) continue;
+        double v0 = d0[c], v1 = d1[c];
+        v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+        if (q == 0) { atomicAdd(&s_red[16 * c + r], v0); atomicAdd(&s_red[ncols + 16 * c + r], v1); }
+    }
+    __syncthreads();
+    const long slot = wg % (unsigned)slots;
+    for (int e = tid; e < 2 * ncols; e += nthreads) {
+        const int which = e >= ncols ? 1 : 0, col = e - which * ncols;
+        unsafeAtomicAdd(&stats[(slot * 2 + which) * cout + col_w0 + col], s_red[e]);
+    }
+}
 
 __device__ __forceinline__ unsigned short f2bf(float f)
 {
@@ -216,6 +247,8 @@ __global__ __launch_bounds__(512) void k_dense_conv(DenseArgs g)
     }
     // epilogue: D[row 4q + i][col r]; row = output u_x = ux0 + 4q + i of block (ry, rz)
     const bool split = g.slab != nullptr;
+    const bool stats = g.stats != nullptr && !split;
+    double d0[4] = {0.0, 0.0, 0.0, 0.0}, d1[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int uz = uz0 + rz[i], uy = uy0 + ry[i];
@@ -237,11 +270,14 @@ __global__ __launch_bounds__(512) void k_dense_conv(DenseArgs g)
                 } else {
                     const int ox = g.p[2] + g.os[2] * ux;
                     const long row = (long)b * g.Out[0] * g.Out[1] * g.Out[2] + ((long)oz * g.Out[1] + oy) * g.Out[2] + ox;
-                    g.y[row * g.ldy + col] = acc[i][c][k] + bv;
+                    const float v = acc[i][c][k] + bv;
+                    g.y[row * g.ldy + col] = v;
+                    if (stats) { d0[c] += (double)v; d1[c] += (double)v * (double)v; }
                 }
             }
         }
     }
+    if (stats) dense_stats_flush<4>(d0, d1, cb_lo, cb_hi, ncols, col_w0, g.cout, g.stats, g.stat_slots, blockIdx.x, smem_raw);
 }
 
 // ---- fast path: 3 x 3 x 3 taps, unit strides, 16 row blocks (tile 16 x 4 x 4, box 18 x 6 x 6) ----------------------------
@@ -379,6 +415,10 @@ __global__ __launch_bounds__(512) void k_dense_conv3(DenseArgs g)
         }
     }
     const bool split = g.slab != nullptr;
+    const bool stats = g.stats != nullptr && !split;
+    double d0[NCB], d1[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) { d0[c] = 0.0; d1[c] = 0.0; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rb = 2 * wave + i;
@@ -396,31 +436,62 @@ __global__ __launch_bounds__(512) void k_dense_conv3(DenseArgs g)
                 const int ux = ux0 + 4 * q + k;
                 if (ux >= g.Sub[2]) continue;
                 if (split) g.slab[((long)blockIdx.z * nsub + srow0 + ux) * g.cout + col] = acc[i][c][k];
-                else g.y[(rowz + ux) * g.ldy + col] = acc[i][c][k] + bv;
+                else {
+                    const float v = acc[i][c][k] + bv;
+                    g.y[(rowz + ux) * g.ldy + col] = v;
+                    if (stats) { d0[c] += (double)v; d1[c] += (double)v * (double)v; }
+                }
             }
         }
     }
+    if (stats) dense_stats_flush<NCB>(d0, d1, 0, NCB, NCOLS, col_w0, g.cout, g.stats, g.stat_slots, blockIdx.x, smem_raw);
 }
 
 // y[out row of sub-grid row][col] = bias + slab[0] + slab[1] + ... (fixed order)
-__global__ void k_dense_splitk_reduce(DenseArgs g, int Z)
+// With g.stats the launch is grid-strided (256 % (cout / 4) == 0: a thread keeps its 4 columns), the column sums of y stay in
+// registers (fp64), are combined per workgroup through LDS and added to the slab like dense_stats_flush does.
+__global__ __launch_bounds__(256) void k_dense_splitk_reduce(DenseArgs g, int Z)
 {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double s_red[256 * 8];
     const int c4 = g.cout / 4;
     const long nsub = (long)g.B * g.Sub[0] * g.Sub[1] * g.Sub[2];
-    if (e >= nsub * c4) return;
-    const int k4 = (int)(e % c4);
-    long v = e / c4;
-    const long srow = v;
-    const int ux = (int)(v % g.Sub[2]); v /= g.Sub[2];
-    const int uy = (int)(v % g.Sub[1]); v /= g.Sub[1];
-    const int uz = (int)(v % g.Sub[0]); const int b = (int)(v / g.Sub[0]);
-    f32x4 s = g.bias ? *(const f32x4 *)(g.bias + 4 * k4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < Z; ++z) s += *(const f32x4 *)(g.slab + ((long)z * nsub + srow) * g.cout + 4 * k4);
-    const long row = (long)b * g.Out[0] * g.Out[1] * g.Out[2] +
-                     ((long)(g.p[0] + g.os[0] * uz) * g.Out[1] + (g.p[1] + g.os[1] * uy)) * g.Out[2] + (g.p[2] + g.os[2] * ux);
-    float *dst = g.y + row * g.ldy + 4 * k4;
-    dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2]; dst[3] = s[3];
+    const long total = nsub * c4;
+    const bool stats = g.stats != nullptr;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int k4 = (int)(e % c4);
+        long v = e / c4;
+        const long srow = v;
+        const int ux = (int)(v % g.Sub[2]); v /= g.Sub[2];
+        const int uy = (int)(v % g.Sub[1]); v /= g.Sub[1];
+        const int uz = (int)(v % g.Sub[0]); const int b = (int)(v / g.Sub[0]);
+        f32x4 s = g.bias ? *(const f32x4 *)(g.bias + 4 * k4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < Z; ++z) s += *(const f32x4 *)(g.slab + ((long)z * nsub + srow) * g.cout + 4 * k4);
+        const long row = (long)b * g.Out[0] * g.Out[1] * g.Out[2] +
+                         ((long)(g.p[0] + g.os[0] * uz) * g.Out[1] + (g.p[1] + g.os[1] * uy)) * g.Out[2] + (g.p[2] + g.os[2] * ux);
+        float *dst = g.y + row * g.ldy + 4 * k4;
+        dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2]; dst[3] = s[3];
+        if (stats) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] += (double)s[k]; a[4 + k] += (double)s[k] * (double)s[k]; }
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_red[k * 256 + threadIdx.x] = a[k];
+    __syncthreads();
+    if ((int)threadIdx.x < c4) {      // thread t < c4 owns columns 4t..4t+3: its peers are t + j * c4
+        double r8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int j = threadIdx.x; j < 256; j += c4)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r8[k] += s_red[k * 256 + j];
+        const long slot = blockIdx.x % (unsigned)g.stat_slots;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsafeAtomicAdd(&g.stats[(slot * 2 + 0) * g.cout + 4 * threadIdx.x + k], r8[k]);
+            unsafeAtomicAdd(&g.stats[(slot * 2 + 1) * g.cout + 4 * threadIdx.x + k], r8[4 + k]);
+        }
+    }
 }
 
 // split factor of a launch: only when the output tiles alone leave most CUs idle
@@ -447,16 +518,17 @@ extern "C" int64_t urn_dense_conv_scratch_bytes(int cout, int batch, const urn_d
 }
 
 extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float *wt, const float *bias, float *y, int64_t ldy,
-                              int cout, int batch, const urn_dense_geom *gm, int precision, void *scratch, int64_t scratch_bytes,
-                              void *stream)
+                              int cout, int batch, const urn_dense_geom *gm, int precision, double *stats, int stat_slots,
+                              void *scratch, int64_t scratch_bytes, void *stream)
 {
     URN_CHECK_ARG(x && wt && y && gm, "null pointer");
+    URN_CHECK_ARG(!stats || (stat_slots > 0 && 256 % (cout / 4) == 0), "statistics: slots > 0 and cout / 4 a divisor of 256");
     URN_CHECK_ARG(cin > 0 && cout > 0 && cin % 16 == 0 && cout % 16 == 0 && batch > 0, "channel counts must be multiples of 16");
     URN_CHECK_ARG(ldx >= cin && ldy >= cout && ldx % 4 == 0, "row strides");
     DenseArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.ldx = (long)ldx; a.ldy = (long)ldy; a.cin = cin; a.cout = cout; a.B = batch;
-    a.mode = gm->mode;
+    a.mode = gm->mode; a.stats = stats; a.stat_slots = stat_slots;
     for (int d = 0; d < 3; ++d) {
         a.In[d] = gm->In[d]; a.Out[d] = gm->Out[d]; a.Sub[d] = gm->Sub[d]; a.p[d] = gm->p[d]; a.os[d] = gm->os[d]; a.s[d] = gm->s[d];
         a.nt[d] = gm->nt[d]; a.kdim[d] = gm->kdim[d];
@@ -523,6 +595,9 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
     dense_plan_split(tiles * gy, cin / (16 * kc), ntaps, a.zc, a.zt);
     const int Z = a.zc * a.zt;
     const long nsub = (long)batch * a.Sub[0] * a.Sub[1] * a.Sub[2];
+    // the split reduce: one element per thread, or (statistics) grid-strided with at most 1024 workgroups
+    long reduce_blocks = urn_cdiv(nsub * (cout / 4), 256);
+    if (stats && reduce_blocks > 1024) reduce_blocks = 1024;
     if (Z > 1 && (!scratch || scratch_bytes < (int64_t)Z * nsub * cout * 4)) { a.zc = a.zt = 1; }   // no scratch: unsplit
     a.slab = a.zc * a.zt > 1 ? (float *)scratch : nullptr;
     const dim3 grid((unsigned)tiles, gy, a.zc * a.zt), block(a.NRB == 16 ? 512 : 128 * (int)(ncols / 16));
@@ -575,7 +650,7 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
 #define URN_D3(P, K, N, R) if (precision == P && kc3 == K && ncb == N && rev == R) { \
                     if (!attr3) (void)hipFuncSetAttribute((const void *)k_dense_conv3<P, K, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                     hipLaunchKernelGGL((k_dense_conv3<P, K, N, R>), grid3, dim3(512), lds3, st, a); \
-                    if (a.slab) hipLaunchKernelGGL(k_dense_splitk_reduce, dim3(urn_cdiv(nsub * (cout / 4), 256)), dim3(256), 0, st, a, a.zc * a.zt); \
+                    if (a.slab) hipLaunchKernelGGL(k_dense_splitk_reduce, dim3(reduce_blocks), dim3(256), 0, st, a, a.zc * a.zt); \
                     URN_LAUNCH_CHECK(); return URN_OK; }
 #define URN_D3K(P, R) URN_D3(P, 1, 1, R) URN_D3(P, 1, 2, R) URN_D3(P, 1, 3, R) URN_D3(P, 1, 4, R) URN_D3(P, 2, 1, R) URN_D3(P, 2, 2, R) URN_D3(P, 2, 3, R) URN_D3(P, 2, 4, R) \
                     URN_D3(P, 4, 1, R) URN_D3(P, 4, 2, R) URN_D3(P, 4, 3, R) URN_D3(P, 4, 4, R)
@@ -588,7 +663,7 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
     if (precision) hipLaunchKernelGGL(k_dense_conv<1>, grid, block, lds, st, a);
     else hipLaunchKernelGGL(k_dense_conv<0>, grid, block, lds, st, a);
     if (a.slab)
-        hipLaunchKernelGGL(k_dense_splitk_reduce, dim3(urn_cdiv(nsub * (cout / 4), 256)), dim3(256), 0, st, a, a.zc * a.zt);
+        hipLaunchKernelGGL(k_dense_splitk_reduce, dim3(reduce_blocks), dim3(256), 0, st, a, a.zc * a.zt);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
@@ -969,6 +1044,33 @@ __global__ void k_dense_dw_reduce(const float *__restrict__ slab, int S, long n,
     *(f32x4 *)(dw + e) += v;
 }
 
+// the same sum written (not accumulated) in torch's parameter layout: element [tap][ix][iy] of the slab layout goes to
+// out[(iy * vx + ix) * ntap + tap] for ix < vx, iy < vy (the zero-padded channels are dropped) -- nn.Conv weight
+// (cout, cin, taps) with x = input, y = output channels, nn.ConvTranspose weight (cin, cout, taps) with the roles swapped.
+__global__ void k_dense_dw_reduce_t(const float *__restrict__ slab, int S, long n, int cx, int cy, int vx, int vy, int ntap,
+                                    float *__restrict__ out)
+{
+    const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= n) return;
+    const int iy = (int)(e % cy);
+    const long r = e / cy;
+    const int ix = (int)(r % cx), tap = (int)(r / cx);
+    if (ix >= vx || iy >= vy) return;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        f32x4 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = *(const f32x4 *)(slab + (long)(s + k) * n + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += p[k];
+    }
+    for (; s < S; ++s) v += *(const f32x4 *)(slab + (long)s * n + e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (iy + k < vy) out[((long)(iy + k) * vx + ix) * ntap + tap] = v[k];
+}
+
 extern "C" int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, const int *k, int cin, int cout)
 {
     if (!out_dims || !k || cin <= 0 || cout <= 0) return -1;
@@ -981,9 +1083,12 @@ extern "C" int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, co
 
 extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *dy, int64_t ld_dy, int cout, int batch,
                             const int *in_dims, const int *out_dims, const int *k, const int *s, const int *lo, int mode,
-                            float *dw, void *scratch, int64_t scratch_bytes, int precision, void *stream)
+                            float *dw, int dw_layout, int cin_valid, int cout_valid, void *scratch, int64_t scratch_bytes,
+                            int precision, void *stream)
 {
     URN_CHECK_ARG(x && dy && dw && scratch && in_dims && out_dims && k && s && lo, "null pointer");
+    URN_CHECK_ARG(dw_layout == 0 || (dw_layout == 1 && cin_valid > 0 && cin_valid <= cin && cout_valid > 0 && cout_valid <= cout),
+                  "dw_layout 0 ([tap][cin][cout], accumulated) or 1 (torch layout, written) with the valid channel counts");
     URN_CHECK_ARG(cin > 0 && cout > 0 && cin % 16 == 0 && cout % 16 == 0 && batch > 0 && ldx >= cin && ld_dy >= cout && ldx % 4 == 0 && ld_dy % 4 == 0,
                   "channel counts must be multiples of 16");
     DenseDwArgs a;
@@ -1038,7 +1143,11 @@ extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *d
         if (precision) hipLaunchKernelGGL(k_dense_dw<1>, grid, block, lds, st, a);
         else hipLaunchKernelGGL(k_dense_dw<0>, grid, block, lds, st, a);
     }
-    hipLaunchKernelGGL(k_dense_dw_reduce, dim3(urn_cdiv((n + 3) / 4, 256)), dim3(256), 0, st, (const float *)scratch, (int)S, n, dw);
+    if (dw_layout == 1)
+        hipLaunchKernelGGL(k_dense_dw_reduce_t, dim3(urn_cdiv((n + 3) / 4, 256)), dim3(256), 0, st, (const float *)scratch, (int)S, n, cin,
+                           cout, cin_valid, cout_valid, ntap, dw);
+    else
+        hipLaunchKernelGGL(k_dense_dw_reduce, dim3(urn_cdiv((n + 3) / 4, 256)), dim3(256), 0, st, (const float *)scratch, (int)S, n, dw);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }

@@ -1,0 +1,255 @@
+// Row passes of the dense U-ResNet around its convolutions (reference uresnet/models/uresnet_dense.py:72-83: every
+// convolution is followed by a batch-statistics BatchNorm; a ResNetModule ends in relu(shortcut + residual), :82):
+//
+//   forward   out = [relu]( raw * scale + shift  [+ res | + res * res_scale + res_shift] )
+//             ONE pass for BatchNorm-apply + residual add + ReLU; the shortcut branch is either the module's input (identity)
+//             or the raw output of the 1x1 shortcut convolution with its own BatchNorm folded in.  The statistics behind
+//             scale / shift come from the producing convolution's epilogue (urn_dense_conv: stats), not from a pass of
+//             their own.
+//   backward  g = d_out * [out > 0];  reduce: (sum g, sum g * xhat) per channel for the main BatchNorm and, with a shortcut
+//             BatchNorm, (sum g, sum g * xhat_s) for it -- one pass over d_out, out, raw (, res_raw);
+//             apply:  d_raw = gamma * invstd * (g - c0 - xhat * c1),  d_res = the same for the shortcut BatchNorm, or g itself
+//             for an identity shortcut -- one pass, two outputs.
+//
+// Row matrices (n, c) fp32, dense rows; c % 4 == 0 and 256 % (c / 4) == 0 (a thread keeps its four channels while it strides
+// over the rows, so the per-channel constants live in registers).  Partial sums are fp64, combined per workgroup through LDS
+// and added with fp64 atomics into slot (workgroup % slots) of a [slots][2][c] slab (the layout urn_bn_finalize_* read).
+#include "urn_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *(const f32x4 *)p; }
+
+__global__ __launch_bounds__(256) void k_dbn_fwd(const float *__restrict__ raw, const float *__restrict__ scale,
+                                                 const float *__restrict__ shift, const float *__restrict__ res,
+                                                 const float *__restrict__ res_scale, const float *__restrict__ res_shift, int relu,
+                                                 float *__restrict__ out, long total4, int c4)
+{
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int k4 = (int)(e % c4);
+    const f32x4 a = ld4(scale + 4 * k4), b = ld4(shift + 4 * k4);
+    f32x4 ra = (f32x4){1.f, 1.f, 1.f, 1.f}, rb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (res_scale) { ra = ld4(res_scale + 4 * k4); rb = ld4(res_shift + 4 * k4); }
+    for (; e < total4; e += 4 * stride) {
+        f32x4 v[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long eu = e + u * stride < total4 ? e + u * stride : e;
+            v[u] = ld4(raw + 4 * eu);
+            if (res) r[u] = ld4(res + 4 * eu);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e + u * stride >= total4) break;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = fmaf(v[u][k], a[k], b[k]);
+                if (res) t += fmaf(r[u][k], ra[k], rb[k]);
+                o[k] = relu ? fmaxf(t, 0.f) : t;
+            }
+            *(f32x4 *)(out + 4 * (e + u * stride)) = o;
+        }
+    }
+}
+
+// sums[slot][0][c] += sum g, sums[slot][1][c] += sum g * xhat; res_sums likewise with xhat of the shortcut BatchNorm
+__global__ __launch_bounds__(256) void k_dbn_bwd_reduce(const float *__restrict__ dout, const float *__restrict__ out,
+                                                        const float *__restrict__ raw, const float *__restrict__ mean,
+                                                        const float *__restrict__ invstd, const float *__restrict__ res_raw,
+                                                        const float *__restrict__ res_mean, const float *__restrict__ res_invstd,
+                                                        long total4, int c4, double *sums, double *res_sums, int slots)
+{
+    __shared__ double s_red[12 * 256];
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int k4 = (int)(e % c4), c = 4 * c4;
+    const f32x4 mu = ld4(mean + 4 * k4), is = ld4(invstd + 4 * k4);
+    f32x4 rmu = (f32x4){0.f, 0.f, 0.f, 0.f}, ris = rmu;
+    if (res_raw) { rmu = ld4(res_mean + 4 * k4); ris = ld4(res_invstd + 4 * k4); }
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (; e < total4; e += 2 * stride) {
+        f32x4 g[2], o[2], x[2], xr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long eu = e + u * stride < total4 ? e + u * stride : e;
+            g[u] = ld4(dout + 4 * eu);
+            if (out) o[u] = ld4(out + 4 * eu);
+            x[u] = ld4(raw + 4 * eu);
+            if (res_raw) xr[u] = ld4(res_raw + 4 * eu);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (e + u * stride >= total4) break;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gv = (out && !(o[u][k] > 0.f)) ? 0.f : g[u][k];
+                s0[k] += (double)gv;
+                s1[k] += (double)gv * (((double)x[u][k] - (double)mu[k]) * (double)is[k]);
+                if (res_raw) s2[k] += (double)gv * (((double)xr[u][k] - (double)rmu[k]) * (double)ris[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s_red[(0 + k) * 256 + threadIdx.x] = s0[k];
+        s_red[(4 + k) * 256 + threadIdx.x] = s1[k];
+        s_red[(8 + k) * 256 + threadIdx.x] = s2[k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < c4) {
+        double r[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) r[k] = 0.0;
+        for (int j = threadIdx.x; j < 256; j += c4)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) r[k] += s_red[k * 256 + j];
+        const long slot = blockIdx.x % (unsigned)slots;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col = 4 * threadIdx.x + k;
+            unsafeAtomicAdd(&sums[(slot * 2 + 0) * c + col], r[k]);
+            unsafeAtomicAdd(&sums[(slot * 2 + 1) * c + col], r[4 + k]);
+            if (res_sums) {
+                unsafeAtomicAdd(&res_sums[(slot * 2 + 0) * c + col], r[k]);
+                unsafeAtomicAdd(&res_sums[(slot * 2 + 1) * c + col], r[8 + k]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dbn_bwd_apply(const float *__restrict__ dout, const float *__restrict__ out,
+                                                       const float *__restrict__ raw, const float *__restrict__ gamma,
+                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                       const float *__restrict__ c0, const float *__restrict__ c1,
+                                                       const float *__restrict__ res_raw, const float *__restrict__ res_gamma,
+                                                       const float *__restrict__ res_mean, const float *__restrict__ res_invstd,
+                                                       const float *__restrict__ rc0, const float *__restrict__ rc1,
+                                                       float *__restrict__ d_raw, float *__restrict__ d_res, long total4, int c4)
+{
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int k4 = (int)(e % c4);
+    const f32x4 mu = ld4(mean + 4 * k4), is = ld4(invstd + 4 * k4), ga = ld4(gamma + 4 * k4), a0 = ld4(c0 + 4 * k4), a1 = ld4(c1 + 4 * k4);
+    f32x4 rmu = mu, ris = is, rga = ga, b0 = a0, b1 = a1;
+    if (res_raw) { rmu = ld4(res_mean + 4 * k4); ris = ld4(res_invstd + 4 * k4); rga = ld4(res_gamma + 4 * k4); b0 = ld4(rc0 + 4 * k4); b1 = ld4(rc1 + 4 * k4); }
+    for (; e < total4; e += 2 * stride) {
+        f32x4 g[2], o[2], x[2], xr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long eu = e + u * stride < total4 ? e + u * stride : e;
+            g[u] = ld4(dout + 4 * eu);
+            if (out) o[u] = ld4(out + 4 * eu);
+            x[u] = ld4(raw + 4 * eu);
+            if (res_raw) xr[u] = ld4(res_raw + 4 * eu);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (e + u * stride >= total4) break;
+            f32x4 dr, ds;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gv = (out && !(o[u][k] > 0.f)) ? 0.f : g[u][k];
+                const float xh = (x[u][k] - mu[k]) * is[k];
+                dr[k] = ga[k] * is[k] * (gv - a0[k] - xh * a1[k]);
+                if (res_raw) {
+                    const float xs = (xr[u][k] - rmu[k]) * ris[k];
+                    ds[k] = rga[k] * ris[k] * (gv - b0[k] - xs * b1[k]);
+                } else {
+                    ds[k] = gv;
+                }
+            }
+            *(f32x4 *)(d_raw + 4 * (e + u * stride)) = dr;
+            if (d_res) *(f32x4 *)(d_res + 4 * (e + u * stride)) = ds;
+        }
+    }
+}
+
+// one 16-lane group per (BatchNorm, channel): the lanes sweep the slots, a fixed shuffle tree adds them
+__global__ __launch_bounds__(256) void k_dbn_bwd_finalize(const double *__restrict__ sums, int nb, int slots, double inv_n, int c,
+                                                          float *__restrict__ out)
+{
+    const int e = (blockIdx.x * 256 + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const bool ok = e < nb * c;
+    const int b = ok ? e / c : 0, col = ok ? e - b * c : 0;
+    const double *p = sums + (long)b * slots * 2 * c + col;
+    double v0 = 0.0, v1 = 0.0;
+    for (int s = l; s < slots; s += 16) { v0 += p[(long)(2 * s) * c]; v1 += p[(long)(2 * s + 1) * c]; }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) { v0 += __shfl_xor(v0, m); v1 += __shfl_xor(v1, m); }
+    if (!ok || l != 0) return;
+    float *o = out + (long)b * 4 * c + col;
+    o[0] = (float)v1;              // dgamma = sum g * xhat
+    o[c] = (float)v0;              // dbeta  = sum g
+    o[2 * c] = (float)(v0 * inv_n);
+    o[3 * c] = (float)(v1 * inv_n);
+}
+
+int ew_blocks(long total4)
+{
+    long b = urn_cdiv(total4, 256L * 8);      // >= 8 row groups per thread where the tensor has them
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+bool ew_shape_ok(int64_t n, int c) { return n >= 0 && c > 0 && c % 4 == 0 && 256 % (c / 4) == 0; }
+
+}   // namespace
+
+extern "C" int urn_dense_bn_act_fwd(const float *raw, const float *scale, const float *shift, const float *res,
+                                    const float *res_scale, const float *res_shift, int relu, float *out, int64_t n, int c,
+                                    void *stream)
+{
+    URN_CHECK_ARG(ew_shape_ok(n, c), "c must be a multiple of 4 with 256 % (c / 4) == 0");
+    if (n == 0) return URN_OK;
+    URN_CHECK_ARG(raw && scale && shift && out && (!res_scale || (res && res_shift)), "null pointer");
+    const long total4 = (long)n * (c / 4);
+    hipLaunchKernelGGL(k_dbn_fwd, dim3(ew_blocks(total4)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, res, res_scale,
+                       res_shift, relu, out, total4, c / 4);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_dense_bn_act_bwd_reduce(const float *d_out, const float *out, const float *raw, const float *mean,
+                                           const float *invstd, const float *res_raw, const float *res_mean,
+                                           const float *res_invstd, int64_t n, int c, double *sums, double *res_sums, int slots,
+                                           void *stream)
+{
+    URN_CHECK_ARG(ew_shape_ok(n, c) && slots > 0, "c must be a multiple of 4 with 256 % (c / 4) == 0; slots > 0");
+    if (n == 0) return URN_OK;
+    URN_CHECK_ARG(d_out && raw && mean && invstd && sums && (!res_raw || (res_mean && res_invstd && res_sums)), "null pointer");
+    const long total4 = (long)n * (c / 4);
+    hipLaunchKernelGGL(k_dbn_bwd_reduce, dim3(ew_blocks(total4)), dim3(256), 0, (hipStream_t)stream, d_out, out, raw, mean, invstd,
+                       res_raw, res_mean, res_invstd, total4, c / 4, sums, res_raw ? res_sums : nullptr, slots);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_dense_bn_bwd_finalize(const double *sums, int nb, int slots, int64_t n, int c, float *out, void *stream)
+{
+    URN_CHECK_ARG(sums && out && (nb == 1 || nb == 2) && slots > 0 && c > 0 && n >= 0, "bad argument");
+    hipLaunchKernelGGL(k_dbn_bwd_finalize, dim3(urn_cdiv((long)nb * c * 16, 256)), dim3(256), 0, (hipStream_t)stream, sums, nb, slots,
+                       n > 0 ? 1.0 / (double)n : 0.0, c, out);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_dense_bn_act_bwd_apply(const float *d_out, const float *out, const float *raw, const float *gamma,
+                                          const float *mean, const float *invstd, const float *coef0, const float *coef1,
+                                          const float *res_raw, const float *res_gamma, const float *res_mean,
+                                          const float *res_invstd, const float *res_coef0, const float *res_coef1, float *d_raw,
+                                          float *d_res, int64_t n, int c, void *stream)
+{
+    URN_CHECK_ARG(ew_shape_ok(n, c), "c must be a multiple of 4 with 256 % (c / 4) == 0");
+    if (n == 0) return URN_OK;
+    URN_CHECK_ARG(d_out && raw && gamma && mean && invstd && coef0 && coef1 && d_raw, "null pointer");
+    URN_CHECK_ARG(!res_raw || (res_gamma && res_mean && res_invstd && res_coef0 && res_coef1 && d_res), "null pointer (shortcut BatchNorm)");
+    const long total4 = (long)n * (c / 4);
+    hipLaunchKernelGGL(k_dbn_bwd_apply, dim3(ew_blocks(total4)), dim3(256), 0, (hipStream_t)stream, d_out, out, raw, gamma, mean,
+                       invstd, coef0, coef1, res_raw, res_gamma, res_mean, res_invstd, res_coef0, res_coef1, d_raw, d_res, total4,
+                       c / 4);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}

@@ -41,7 +41,60 @@ def _geom(In, Out, Sub, p, os, s, taps, kdim, mode):
 _SCRATCH = {}
 
 
-def _launch(x, ldx, cin, wt, bias, y, ldy, cout, B, g):
+STAT_SLOTS = 256     # rows of a statistics slab (urn_dense_conv: stats); the 128^3 levels launch 32768 workgroups
+
+
+class _ZeroPool(object):
+    """fp64 accumulation slabs (statistics of ~60 convolutions, BatchNorm-backward sums) come out of ONE buffer that is
+    zeroed by one memset when the network's forward pass begins (pool_begin) instead of ~100 small fills per step.  Slabs are
+    scratch: consumed on the same stream before anything reuses the buffer, never handed to autograd as results."""
+
+    def __init__(self):
+        self.buf, self.off, self.want = None, 0, 8 << 20
+
+    def begin(self, device):
+        if self.buf is None or self.buf.device != device or self.buf.numel() * 8 < self.want:
+            self.buf = torch.empty(self.want // 8, dtype=torch.float64, device=device)
+        self.buf.zero_()
+        self.off = 0
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= d
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            if self.buf is not None and self.buf.device == device:
+                self.want = max(self.want, 2 * (self.off + n) * 8)      # grow at the next pool_begin
+                self.off += n
+            return torch.zeros(shape, dtype=torch.float64, device=device)
+        t = self.buf[self.off:self.off + n].view(shape)
+        self.off += (n + 31) & ~31
+        return t
+
+
+_POOL = _ZeroPool()
+
+
+def pool_begin(device):
+    _POOL.begin(device)
+
+
+def zeros_f64(shape, device):
+    return _POOL.take(tuple(shape), device)
+
+
+def new_stats(cout_p, device):
+    """zeroed [STAT_SLOTS][2][cout_p] fp64 slab for the column statistics a convolution's epilogue accumulates"""
+    return zeros_f64((STAT_SLOTS, 2, cout_p), device)
+
+
+def stats_ok(c):
+    """channel counts the fused statistics / row passes take (a thread keeps its 4 channels: 256 % (c / 4) == 0)"""
+    cp = c + (-c) % 16
+    return c % 4 == 0 and 256 % (c // 4) == 0 and 256 % (cp // 4) == 0
+
+
+def _launch(x, ldx, cin, wt, bias, y, ldy, cout, B, g, stats=None):
     L = _l.load()
     sb = L.urn_dense_conv_scratch_bytes(cout, B, ctypes.byref(g))
     key = (x.device, sb > 256)
@@ -50,7 +103,8 @@ def _launch(x, ldx, cin, wt, bias, y, ldy, cout, B, g):
         # split-contraction slabs of the small launches (same stream: reuse is ordered); the big launches never split
         scratch = _SCRATCH[key] = torch.empty(max(sb, 256), dtype=torch.uint8, device=x.device)
     _l.check(L.urn_dense_conv(x.data_ptr(), ldx, cin, wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), ldy,
-                              cout, B, ctypes.byref(g), PRECISION, scratch.data_ptr(), scratch.numel(), _l.stream()), 'dense_conv')
+                              cout, B, ctypes.byref(g), PRECISION, None if stats is None else stats.data_ptr(),
+                              0 if stats is None else stats.shape[0], scratch.data_ptr(), scratch.numel(), _l.stream()), 'dense_conv')
 
 
 def _colsum(rows, c):
@@ -141,7 +195,10 @@ class DenseConvFunction(torch.autograd.Function):
     """y rows = Conv(k, stride) of the replicate-padded volume (+ bias).  rows: (B * prod(spatial), Cin)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, B, spatial, stride, pad_lo, pad_hi):
+    def forward(ctx, rows, weight, bias, B, spatial, stride, pad_lo, pad_hi, stats=None, bias_grad=True):
+        """stats: zeroed new_stats(cout_p) slab to receive the column statistics of y (not differentiable);
+        bias_grad False: the bias feeds a batch-statistics BatchNorm, its gradient is identically zero (the sum of a
+        BatchNorm's input gradient over the rows vanishes) and is returned as zeros without the column-sum pass"""
         _l.require_gpu(rows)
         rows = rows.contiguous()
         nd = len(spatial)
@@ -157,9 +214,10 @@ class DenseConvFunction(torch.autograd.Function):
         bias_p = None if bias is None else _pad16(bias.contiguous(), 0)
         n_out = B * Out[0] * Out[1] * Out[2]
         y = torch.empty((n_out, cout_p), dtype=torch.float32, device=rows.device)
-        _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, fwd)
+        _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, fwd, stats)
         ctx.save_for_backward(xin, weight)
         ctx.meta = (B, tuple(spatial), stride, Out, bwd, padinfo, cin, cout, cin_p, cout_p, bias is not None)
+        ctx.bias_grad = bias_grad
         ctx.out_spatial = tuple(Out[3 - nd:])
         return y[:, :cout].contiguous() if cout_p != cout else y
 
@@ -190,21 +248,21 @@ class DenseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = dense_conv_dw(xin, dy, weight.shape, B, spatial, stride, lo, Out, cin, cout)
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, cout)
-        return dx, dw, db, None, None, None, None, None
+            db = _colsum(dy, cout) if ctx.bias_grad else torch.zeros(cout, dtype=torch.float32, device=dy.device)
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def _dw_call(x, cx, dy, cy, B, in_dims, out_dims, kk, ss, lo, mode):
-    """dw[tap][cx][cy] = sum_o x[in(o, tap)] (x) dy[o]  (two stages, deterministic); returns the (ntap, cx, cy) tensor"""
+def _dw_call(x, cx, dy, cy, B, in_dims, out_dims, kk, ss, lo, mode, vx, vy, wshape):
+    """dw[tap][cx][cy] = sum_o x[in(o, tap)] (x) dy[o]  (two stages, deterministic), written in torch's parameter layout
+    (vy, vx, taps) = wshape -- the zero-padded channels beyond vx / vy dropped"""
     L = _l.load()
     I3 = ctypes.c_int * 3
-    ntap = kk[0] * kk[1] * kk[2]
-    dwt = torch.zeros((ntap, cx, cy), dtype=torch.float32, device=x.device)
+    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
     sb = L.urn_dense_dw_scratch_bytes(B, I3(*out_dims), I3(*kk), cx, cy)
     scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
     _l.check(L.urn_dense_dw(x.data_ptr(), cx, cx, dy.data_ptr(), cy, cy, B, I3(*in_dims), I3(*out_dims), I3(*kk), I3(*ss),
-                            I3(*lo), mode, dwt.data_ptr(), scratch.data_ptr(), sb, PRECISION, _l.stream()), 'dense_dw')
-    return dwt
+                            I3(*lo), mode, dw.data_ptr(), 1, vx, vy, scratch.data_ptr(), sb, PRECISION, _l.stream()), 'dense_dw')
+    return dw
 
 
 def dense_conv_dw(xin, dy, wshape, B, spatial, stride, lo, Out, cin, cout):
@@ -215,16 +273,14 @@ def dense_conv_dw(xin, dy, wshape, B, spatial, stride, lo, Out, cin, cout):
     real = [False] * (3 - nd) + [True] * nd
     kk = [k if r else 1 for r in real]
     ss = [stride if r else 1 for r in real]
-    dwt = _dw_call(xin, xin.shape[1], dy, dy.shape[1], B, In, Out, kk, ss, lo, 0)
-    # [tap][ci][co] -> torch layout (cout, cin, *k)
-    return dwt[:, :cin, :cout].permute(2, 1, 0).reshape(wshape).contiguous()
+    return _dw_call(xin, xin.shape[1], dy, dy.shape[1], B, In, Out, kk, ss, lo, 0, cin, cout, wshape)
 
 
 class DenseConvTransposeFunction(torch.autograd.Function):
     """y rows = ConvTranspose k3 s2 p1 op1 (+ bias); weight (Cin, Cout, *k) like torch."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, B, spatial):
+    def forward(ctx, rows, weight, bias, B, spatial, stats=None, bias_grad=True):
         _l.require_gpu(rows)
         rows = rows.contiguous()
         nd = len(spatial)
@@ -237,9 +293,10 @@ class DenseConvTransposeFunction(torch.autograd.Function):
         bias_p = None if bias is None else _pad16(bias.contiguous(), 0)
         y = torch.empty((B * Out[0] * Out[1] * Out[2], cout_p), dtype=torch.float32, device=rows.device)
         for g in fwd:
-            _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, g)
+            _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, g, stats)
         ctx.save_for_backward(xin, weight)
         ctx.meta = (B, tuple(spatial), Out, bwd, cin, cout, cin_p, cout_p, bias is not None)
+        ctx.bias_grad = bias_grad
         ctx.out_spatial = tuple(Out[3 - nd:])
         return y[:, :cout].contiguous() if cout_p != cout else y
 
@@ -265,8 +322,7 @@ class DenseConvTransposeFunction(torch.autograd.Function):
             kk = [3 if r else 1 for r in real]
             ss = [2 if r else 1 for r in real]
             lo = [1 if r else 0 for r in real]
-            dwt = _dw_call(dy, cout_p, xin, cin_p, B, Out, In, kk, ss, lo, 1)
-            dw = dwt[:, :cout, :cin].permute(2, 1, 0).reshape(weight.shape).contiguous()
+            dw = _dw_call(dy, cout_p, xin, cin_p, B, Out, In, kk, ss, lo, 1, cout, cin, weight.shape)
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, cout)
-        return dx, dw, db, None, None
+            db = _colsum(dy, cout) if ctx.bias_grad else torch.zeros(cout, dtype=torch.float32, device=dy.device)
+        return dx, dw, db, None, None, None, None

@@ -6,7 +6,11 @@ views).  Convolutions run on the dense implicit-GEMM kernels (csrc/urn_dense.hip
     is part of its addressing; input gradient = the same kernel on the padded volume + urn_dense_fold; weight gradient =
     urn_dense_dw (two stages, deterministic);
   * ConvTranspose k3 s2 p1 op1 (reference :164-172): one call per output parity class (only the valid taps each);
-  * BatchNorm with batch statistics (+ReLU): urn_bn_relu_fwd/bwd over the rows (the sparse path's row kernels).
+  * BatchNorm with batch statistics: the statistics come out of the producing convolution's epilogue (urn_dense_conv:
+    stats), BatchNorm-apply + shortcut add (identity, or the shortcut conv's own BatchNorm) + ReLU are ONE row pass
+    (urn_dense_bn_act_fwd), their gradient two (reduce, apply: urn_dense_bn_act_bwd_*) -- BNActFunction below.  Channel
+    counts those passes do not take (the num_class-wide output layer) use the sparse path's row kernels
+    (urn_bn_relu_fwd/bwd).
 No index tables, no padded copies (the first GPU route ran every conv as a gather convolution over [27][n] int32 tables:
 226 MB per 128^3 conv, 8.4 GB per cfg2 step).  `-prec bf16` (BASELINE configs[1]) rounds the MFMA operands to bf16 in LDS;
 tensors in HBM and the accumulation stay fp32.
@@ -14,6 +18,7 @@ tensors in HBM and the accumulation stay fp32.
 import torch
 
 from . import dense_conv as dc
+from . import lib as _l
 from . import sparse_ops as so
 
 
@@ -50,21 +55,127 @@ def _bn(rows, gamma, beta, eps, relu):
     return so.BNReLUFunction.apply(rows, gamma, beta, None, None, eps, 0.0, bool(relu), True)
 
 
-def conv_bn_act(x, w, b, stride, pad, gamma, beta, eps, relu, residual=None):
+class DeferredBN(object):
+    """raw output of a convolution whose BatchNorm has not been applied: handed to conv_bn_act(residual=...) so that the
+    shortcut branch's BatchNorm, the add and the ReLU of a ResNetModule (reference uresnet_dense.py:72-82) are one pass"""
+
+    def __init__(self, raw, stats, gamma, beta, eps, B, spatial):
+        self.raw, self.stats, self.gamma, self.beta, self.eps, self.B, self.spatial = raw, stats, gamma, beta, eps, B, spatial
+
+
+def _finalize(stats, n, c, eps, gamma, beta):
+    """statistics slab -> (mean, invstd, scale, shift), each (c,) fp32"""
+    L = _l.load()
+    o = torch.empty((4, c), dtype=torch.float32, device=stats.device)
+    _l.check(L.urn_bn_finalize_fwd(stats.data_ptr(), stats.shape[0], n, c, stats.shape[2], float(eps), gamma.data_ptr(),
+                                   beta.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), None, None,
+                                   0.0, _l.stream()), 'bn_finalize_fwd')
+    return o
+
+
+class BNActFunction(torch.autograd.Function):
+    """out = [relu](BN(raw) [+ res | + BN_s(res)]) with the batch statistics already in `stats` (convolution epilogue)"""
+
+    @staticmethod
+    def forward(ctx, raw, gamma, beta, stats, eps, relu, res, res_gamma, res_beta, res_stats, res_eps):
+        L = _l.load()
+        n, c = raw.shape
+        gamma = gamma.contiguous(); beta = beta.contiguous()
+        f = _finalize(stats, n, c, eps, gamma, beta)
+        fr = None
+        if res is not None:
+            res = res.contiguous()
+            if res_stats is not None:
+                res_gamma = res_gamma.contiguous()
+                fr = _finalize(res_stats, n, c, res_eps, res_gamma, res_beta.contiguous())
+        out = torch.empty_like(raw)
+        _l.check(L.urn_dense_bn_act_fwd(raw.data_ptr(), f[2].data_ptr(), f[3].data_ptr(), None if res is None else res.data_ptr(),
+                                        None if fr is None else fr[2].data_ptr(), None if fr is None else fr[3].data_ptr(),
+                                        1 if relu else 0, out.data_ptr(), n, c, _l.stream()), 'dense_bn_act_fwd')
+        ctx.relu, ctx.has_res, ctx.res_bn = bool(relu), res is not None, fr is not None
+        # the shortcut's raw rows are only needed for ITS BatchNorm's xhat
+        ctx.save_for_backward(raw, out if relu else None, gamma, f, res if fr is not None else None,
+                              res_gamma if fr is not None else None, fr)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        raw, out, gamma, f, res_raw, res_gamma, fr = ctx.saved_tensors
+        L = _l.load()
+        n, c = raw.shape
+        d_out = d_out.contiguous()
+        dev = raw.device
+        slots = 64
+        nb = 2 if ctx.res_bn else 1
+        sums = dc.zeros_f64((nb, slots, 2, c), dev)
+        o = torch.empty((8, c), dtype=torch.float32, device=dev)     # dgamma, dbeta, coef0, coef1 (main | shortcut)
+        P = lambda t: None if t is None else t.data_ptr()
+        _l.check(L.urn_dense_bn_act_bwd_reduce(d_out.data_ptr(), P(out), raw.data_ptr(), f[0].data_ptr(), f[1].data_ptr(),
+                                               P(res_raw), None if fr is None else fr[0].data_ptr(),
+                                               None if fr is None else fr[1].data_ptr(), n, c, sums[0].data_ptr(),
+                                               sums[1].data_ptr() if ctx.res_bn else None, slots, _l.stream()), 'dense_bn_act_bwd_reduce')
+        _l.check(L.urn_dense_bn_bwd_finalize(sums.data_ptr(), nb, slots, n, c, o.data_ptr(), _l.stream()), 'dense_bn_bwd_finalize')
+        d_raw = torch.empty_like(raw)
+        d_res = None
+        if ctx.has_res:
+            # identity shortcut without a ReLU: its gradient IS d_out
+            d_res = torch.empty_like(raw) if (ctx.res_bn or ctx.relu) else d_out
+        _l.check(L.urn_dense_bn_act_bwd_apply(d_out.data_ptr(), P(out), raw.data_ptr(), gamma.data_ptr(), f[0].data_ptr(),
+                                              f[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), P(res_raw), P(res_gamma),
+                                              None if fr is None else fr[0].data_ptr(), None if fr is None else fr[1].data_ptr(),
+                                              o[6].data_ptr() if ctx.res_bn else None, o[7].data_ptr() if ctx.res_bn else None,
+                                              d_raw.data_ptr(), d_res.data_ptr() if (ctx.has_res and d_res is not d_out) else None,
+                                              n, c, _l.stream()), 'dense_bn_act_bwd_apply')
+        return (d_raw, o[0], o[1], None, None, None, d_res, o[4] if ctx.res_bn else None, o[5] if ctx.res_bn else None, None, None)
+
+
+def _conv_raw(x, w, b, stride, pad):
+    """convolution with the statistics of its output: (raw rows, stats slab or None, B, out_spatial)"""
     rows, B, spatial = to_rows(x)
-    y, out_spatial = _conv_rows(rows, B, spatial, w, b, stride, pad)
-    if residual is None:
-        y = _bn(y, gamma, beta, eps, relu)
-    else:
+    cout = w.shape[0]
+    fused = dc.stats_ok(cout)
+    stats = dc.new_stats(cout + (-cout) % 16, rows.device) if fused else None
+    lo, hi = (int(pad[0]), int(pad[1])) if len(pad) else (0, 0)
+    y = dc.DenseConvFunction.apply(rows, w, b, B, tuple(spatial), stride, lo, hi, stats, False)
+    k = w.shape[2]
+    out_spatial = tuple((s + lo + hi - k) // stride + 1 for s in spatial)
+    return y, stats, B, out_spatial
+
+
+def conv_bn_act(x, w, b, stride, pad, gamma, beta, eps, relu, residual=None, defer=False):
+    y, stats, B, out_spatial = _conv_raw(x, w, b, stride, pad)
+    if defer and stats is not None:
+        return DeferredBN(y, stats, gamma, beta, eps, B, out_spatial)
+    if stats is None:                       # channel counts the fused passes do not take
+        if isinstance(residual, DeferredBN):
+            residual = from_rows(_bn(residual.raw, residual.gamma, residual.beta, residual.eps, False), B, out_spatial)
+        if residual is None:
+            y = _bn(y, gamma, beta, eps, relu)
+        else:
+            r, _, _ = to_rows(residual)
+            y = _bn(y, gamma, beta, eps, False) + r
+            if relu:
+                y = torch.relu(y)
+        return from_rows(y, B, out_spatial)
+    if isinstance(residual, DeferredBN):
+        y = BNActFunction.apply(y, gamma, beta, stats, eps, relu, residual.raw, residual.gamma, residual.beta, residual.stats,
+                                residual.eps)
+    elif residual is not None:
         r, _, _ = to_rows(residual)
-        y = _bn(y, gamma, beta, eps, False) + r
-        if relu:
-            y = torch.relu(y)
+        y = BNActFunction.apply(y, gamma, beta, stats, eps, relu, r, None, None, None, 0.0)
+    else:
+        y = BNActFunction.apply(y, gamma, beta, stats, eps, relu, None, None, None, None, 0.0)
     return from_rows(y, B, out_spatial)
 
 
 def convT_bn_act(x, w, b, gamma, beta, eps, relu):
     rows, B, spatial = to_rows(x)
-    y = dc.DenseConvTransposeFunction.apply(rows, w, b, B, tuple(spatial))
-    y = _bn(y, gamma, beta, eps, relu)
+    cout = w.shape[1]
+    fused = dc.stats_ok(cout)
+    stats = dc.new_stats(cout + (-cout) % 16, rows.device) if fused else None
+    y = dc.DenseConvTransposeFunction.apply(rows, w, b, B, tuple(spatial), stats, False)
+    if fused:
+        y = BNActFunction.apply(y, gamma, beta, stats, eps, relu, None, None, None, None, 0.0)
+    else:
+        y = _bn(y, gamma, beta, eps, relu)
     return from_rows(y, B, tuple(2 * s for s in spatial))

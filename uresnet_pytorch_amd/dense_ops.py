@@ -34,9 +34,12 @@ def _gpu():
     return _GPU_IMPL
 
 
-def conv_bn_act(x, w, b, stride, pad, gamma, beta, eps, relu, residual=None):
+def conv_bn_act(x, w, b, stride, pad, gamma, beta, eps, relu, residual=None, defer=False):
+    """defer=True (shortcut branch of a ResNetModule): the GPU route may hand back the raw convolution output with its
+    BatchNorm pending (dense_hip.DeferredBN), to be passed as `residual` of the module's last conv_bn_act -- the shortcut's
+    BatchNorm, the add and the ReLU are then one pass.  The CPU route ignores it."""
     if x.is_cuda:
-        y = _gpu().conv_bn_act(x, w, b, stride, pad, gamma, beta, eps, relu, residual)
+        y = _gpu().conv_bn_act(x, w, b, stride, pad, gamma, beta, eps, relu, residual, defer)
         if relu and RELU_RECORD is not None:
             RELU_RECORD(y)
         return y

@@ -115,11 +115,17 @@ SIGNATURES = {
                            c_void_p, c_void_p]),
     'urn_dense_conv_scratch_bytes': (c_i64, [c_int, c_int, c_void_p]),
     'urn_dense_conv': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_void_p,
-                               c_i64, c_void_p]),
+                               c_int, c_void_p, c_i64, c_void_p]),
     'urn_dense_dw_scratch_bytes': (c_i64, [c_int, c_void_p, c_void_p, c_int, c_int]),
     'urn_dense_dw': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_int, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+                             c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_int, c_void_p]),
     'urn_dense_fold': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'urn_dense_bn_act_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_int,
+                                     c_void_p]),
+    'urn_dense_bn_act_bwd_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+                                            c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'urn_dense_bn_bwd_finalize': (c_int, [c_void_p, c_int, c_int, c_i64, c_int, c_void_p, c_void_p]),
+    'urn_dense_bn_act_bwd_apply': (c_int, [c_void_p] * 16 + [c_i64, c_int, c_void_p]),
     'urn_net_create': (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, c_int, ctypes.POINTER(c_void_p)]),
     'urn_net_destroy': (None, [c_void_p]),
     'urn_net_param_count': (c_i64, [c_void_p]),

@@ -30,11 +30,11 @@ def padding(kernel, stride, input_size):
     return (p1, p2,) * (len(input_size) - 2)
 
 
-def _conv_bn(seq, x, relu=False, residual=None):
+def _conv_bn(seq, x, relu=False, residual=None, defer=False):
     """replicate-pad -> conv -> batch-stat BN (-> +residual) (-> ReLU) of a Sequential(conv, bn[, ReLU])."""
     conv, bn = seq[0], seq[1]
     pad = padding(conv.kernel_size[0], conv.stride[0], x.size())
-    return D.conv_bn_act(x, conv.weight, conv.bias, conv.stride[0], pad, bn.weight, bn.bias, bn.eps, relu, residual)
+    return D.conv_bn_act(x, conv.weight, conv.bias, conv.stride[0], pad, bn.weight, bn.bias, bn.eps, relu, residual, defer)
 
 
 class ResNetModule(nn.Module):
@@ -54,7 +54,7 @@ class ResNetModule(nn.Module):
             batch_norm(num_features=num_outputs, momentum=bn_momentum, track_running_stats=False))
 
     def forward(self, input_tensor):
-        shortcut = _conv_bn(self.shortcut, input_tensor) if self.use_shortcut else input_tensor
+        shortcut = _conv_bn(self.shortcut, input_tensor, defer=True) if self.use_shortcut else input_tensor
         residual = _conv_bn(self.residual1, input_tensor)          # no ReLU between the two (reference :78-81)
         return _conv_bn(self.residual2, residual, relu=True, residual=shortcut)   # relu(shortcut + residual)
 
@@ -126,6 +126,7 @@ class UResNet(nn.Module):
             if prec not in ('fp32', 'bf16'):
                 raise RuntimeError('dense kernels: MFMA operand precision fp32 or bf16 (got %s)' % prec)
             _dc.set_precision(prec)
+            _dc.pool_begin(input.device)        # one memset for the step's fp64 accumulation slabs
         conv_feature_map = {}
         net = _conv_bn(self.conv1, input, relu=True)
         conv_feature_map[net.size()[1]] = net            # skip links keyed by channel count (reference :210,214)
