@@ -361,6 +361,16 @@ int urn_dense_bn_act_bwd_apply(const float *d_out, const float *out, const float
                                const float *invstd, const float *coef0, const float *coef1, const float *res_raw,
                                const float *res_gamma, const float *res_mean, const float *res_invstd, const float *res_coef0,
                                const float *res_coef1, float *d_raw, float *d_res, int64_t n, int c, void *stream);
+/* DenseSegmentationLoss of ONE event (reference uresnet_dense.py:246-258) on the device, no host synchronisation: over the n
+ * voxels (logits rows of nc floats, row stride ld; label / data / weight one float per voxel, weight may be NULL), with
+ * mask = data > 1e-6: out[0] = sum(ce * weight * mask) / sum(mask), out[1] = sum(mask * [argmax == label]) / sum(mask).
+ * acc: 3 zeroed doubles (the three sums, kept for the backward), row_lse (n) kept too.
+ * urn_dense_ce_bwd: dlogits (n, nc, dense) = grad_out[0] * weight * mask / sum(mask) * (softmax - onehot(label)). */
+int urn_dense_ce_fwd(const float *logits, int64_t ld, const float *label, const float *data, const float *weight, int64_t n,
+                     int nc, float *row_lse, double *acc, float *out, void *stream);
+int urn_dense_ce_bwd(const float *logits, int64_t ld, const float *label, const float *data, const float *weight,
+                     const float *row_lse, const double *acc, const float *grad_out, int64_t n, int nc, float *dlogits,
+                     void *stream);
 
 /* ------------------------------------------------------------------ whole-network executor
  * The trunk of the sparse model -- everything between scn.InputLayer and torch.nn.Linear at

@@ -182,3 +182,32 @@ def test_dense_bn_act_function_matches_torch(dev, c, n, relu, res):
     used = {'none': 3, 'identity': 4, 'bn': 6}[res]
     for i in range(used):
         assert rel(Q[i].grad, P[i].grad) < 1e-5, names[i]
+
+
+@pytest.mark.parametrize('dim,S,B', [(2, 24, 3), (3, 12, 2)])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_dense_segmentation_loss_on_device_matches_cpu_route(dev, dim, S, B, weighted):
+    """DenseSegmentationLoss: the fused per-event kernel (GPU tensors) against the same class on CPU tensors (the
+    reference's torch ops, uresnet_dense.py:235-260): loss, accuracy, gradient of the logits"""
+    from types import SimpleNamespace
+    from uresnet_pytorch_amd.models import DenseSegmentationLoss
+    nc = 5
+    g = torch.Generator().manual_seed(S + B)
+    crit = DenseSegmentationLoss(SimpleNamespace())
+    logits = torch.randn(B, nc, *([S] * dim), generator=g) * 2
+    data = [(torch.rand(1, *([S] * dim), generator=g) * (torch.rand(1, *([S] * dim), generator=g) > 0.7)).float() for _ in range(B)]
+    label = [torch.randint(0, nc, (1, *([S] * dim)), generator=g).float() for _ in range(B)]
+    weight = [torch.rand(1, *([S] * dim), generator=g) + 0.5 for _ in range(B)] if weighted else None
+    lc = logits.clone().requires_grad_(True)
+    loss_c, acc_c = crit([lc[i] for i in range(B)], data, label, weight)
+    loss_c.backward()
+    # channels-last logits on the device, as the network hands them out
+    rows = logits.permute(0, *range(2, 2 + dim), 1).reshape(-1, nc).to(dev).requires_grad_(True)
+    lg = rows.reshape(B, *([S] * dim), nc).permute(0, dim + 1, *range(1, dim + 1))
+    loss_g, acc_g = crit([lg[i] for i in range(B)], [d.to(dev) for d in data], [l.to(dev) for l in label],
+                         None if weight is None else [w.to(dev) for w in weight])
+    loss_g.backward()
+    assert abs(float(loss_g.detach()) - float(loss_c.detach())) < 1e-5 * abs(float(loss_c.detach()))
+    assert abs(float(acc_g) - float(acc_c)) < 1e-6
+    gc = lc.grad.permute(0, *range(2, 2 + dim), 1).reshape(-1, nc)
+    assert rel(rows.grad, gc) < 1e-5

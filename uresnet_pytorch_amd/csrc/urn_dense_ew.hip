@@ -186,6 +186,70 @@ __global__ __launch_bounds__(256) void k_dbn_bwd_finalize(const double *__restri
     o[3 * c] = (float)(v1 * inv_n);
 }
 
+// DenseSegmentationLoss of one event (reference uresnet_dense.py:246-258) in one pass over the voxels: per voxel the
+// log-sum-exp (kept for the backward), the cross-entropy at the label, the arg-max; sums over the event of
+// ce * weight * mask, mask (= data > 1e-6: the non-zero count) and mask * [argmax == label], fp64, one atomic triple per
+// workgroup.  acc[0..2] must be zero on entry.
+__global__ __launch_bounds__(256) void k_dce_fwd(const float *__restrict__ logits, long ld, const float *__restrict__ label,
+                                                 const float *__restrict__ data, const float *__restrict__ weight, long n, int nc,
+                                                 float *__restrict__ row_lse, double *acc)
+{
+    __shared__ double s_red[3 * 256];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long)gridDim.x * 256) {
+        const float *p = logits + v * ld;
+        float mx = p[0];
+        int am = 0;
+        for (int c = 1; c < nc; ++c) { const float x = p[c]; if (x > mx) { mx = x; am = c; } }   // first maximum, like torch.argmax
+        float se = 0.f;
+        for (int c = 0; c < nc; ++c) se += __expf(p[c] - mx);
+        const float lse = mx + __logf(se);
+        row_lse[v] = lse;
+        const int lab = (int)label[v];
+        if (data[v] > 0.000001f) {
+            const float ce = lse - p[lab];
+            a0 += (double)(weight ? ce * weight[v] : ce);
+            a1 += 1.0;
+            a2 += am == lab ? 1.0 : 0.0;
+        }
+    }
+    s_red[threadIdx.x] = a0; s_red[256 + threadIdx.x] = a1; s_red[512 + threadIdx.x] = a2;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) {
+            s_red[threadIdx.x] += s_red[threadIdx.x + m];
+            s_red[256 + threadIdx.x] += s_red[256 + threadIdx.x + m];
+            s_red[512 + threadIdx.x] += s_red[512 + threadIdx.x + m];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { unsafeAtomicAdd(&acc[0], s_red[0]); unsafeAtomicAdd(&acc[1], s_red[256]); unsafeAtomicAdd(&acc[2], s_red[512]); }
+}
+
+__global__ void k_dce_finalize(const double *acc, float *out)
+{
+    out[0] = (float)(acc[0] / acc[1]);     // 0 / 0 = nan for an event without non-zero voxels, like the reference's division
+    out[1] = (float)(acc[2] / acc[1]);
+}
+
+// dlogits[v][c] = grad * weight * mask / nnz * (softmax(logits[v])[c] - [c == label])
+__global__ __launch_bounds__(256) void k_dce_bwd(const float *__restrict__ logits, long ld, const float *__restrict__ label,
+                                                 const float *__restrict__ data, const float *__restrict__ weight,
+                                                 const float *__restrict__ row_lse, const double *__restrict__ acc,
+                                                 const float *__restrict__ grad, long n, int nc, float *__restrict__ dl)
+{
+    const float gs = (float)((double)grad[0] / acc[1]);
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long)gridDim.x * 256) {
+        const float *p = logits + v * ld;
+        float *o = dl + v * nc;
+        if (!(data[v] > 0.000001f)) { for (int c = 0; c < nc; ++c) o[c] = 0.f; continue; }
+        const float sc = weight ? gs * weight[v] : gs;
+        const float lse = row_lse[v];
+        const int lab = (int)label[v];
+        for (int c = 0; c < nc; ++c) o[c] = sc * (__expf(p[c] - lse) - (c == lab ? 1.f : 0.f));
+    }
+}
+
 int ew_blocks(long total4)
 {
     long b = urn_cdiv(total4, 256L * 8);      // >= 8 row groups per thread where the tensor has them
@@ -250,6 +314,34 @@ extern "C" int urn_dense_bn_act_bwd_apply(const float *d_out, const float *out, 
     hipLaunchKernelGGL(k_dbn_bwd_apply, dim3(ew_blocks(total4)), dim3(256), 0, (hipStream_t)stream, d_out, out, raw, gamma, mean,
                        invstd, coef0, coef1, res_raw, res_gamma, res_mean, res_invstd, res_coef0, res_coef1, d_raw, d_res, total4,
                        c / 4);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_dense_ce_fwd(const float *logits, int64_t ld, const float *label, const float *data, const float *weight,
+                                int64_t n, int nc, float *row_lse, double *acc, float *out, void *stream)
+{
+    URN_CHECK_ARG(logits && label && data && row_lse && acc && out && n >= 0 && nc >= 1 && ld >= nc, "bad argument");
+    long b = urn_cdiv((long)n, 256L * 4);
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    hipLaunchKernelGGL(k_dce_fwd, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, label, data, weight, (long)n, nc,
+                       row_lse, acc);
+    hipLaunchKernelGGL(k_dce_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double *)acc, out);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_dense_ce_bwd(const float *logits, int64_t ld, const float *label, const float *data, const float *weight,
+                                const float *row_lse, const double *acc, const float *grad_out, int64_t n, int nc, float *dlogits,
+                                void *stream)
+{
+    URN_CHECK_ARG(logits && label && data && row_lse && acc && grad_out && dlogits && n >= 0 && nc >= 1 && ld >= nc, "bad argument");
+    if (n == 0) return URN_OK;
+    long b = urn_cdiv((long)n, 256L * 4);
+    if (b > 2048) b = 2048;
+    hipLaunchKernelGGL(k_dce_bwd, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, label, data, weight, row_lse, acc,
+                       grad_out, (long)n, nc, dlogits);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }

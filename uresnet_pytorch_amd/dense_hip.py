@@ -179,3 +179,47 @@ def convT_bn_act(x, w, b, gamma, beta, eps, relu):
     else:
         y = _bn(y, gamma, beta, eps, relu)
     return from_rows(y, B, tuple(2 * s for s in spatial))
+
+
+class DenseCEFunction(torch.autograd.Function):
+    """DenseSegmentationLoss of one event (reference uresnet_dense.py:246-258) as one pass on the device: returns
+    (loss, out) with out = [loss, accuracy] (not differentiable); no host synchronisation."""
+
+    @staticmethod
+    def forward(ctx, logits, label, data, weight):
+        _l.require_gpu(logits)
+        L = _l.load()
+        logits = logits.contiguous()
+        n, nc = logits.shape
+        row_lse = torch.empty(n, dtype=torch.float32, device=logits.device)
+        acc = torch.zeros(3, dtype=torch.float64, device=logits.device)
+        out = torch.empty(2, dtype=torch.float32, device=logits.device)
+        _l.check(L.urn_dense_ce_fwd(logits.data_ptr(), nc, label.data_ptr(), data.data_ptr(), _l.ptr(weight), n, nc,
+                                    row_lse.data_ptr(), acc.data_ptr(), out.data_ptr(), _l.stream()), 'dense_ce_fwd')
+        ctx.save_for_backward(logits, label, data, row_lse, acc)
+        ctx.w = weight
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, gloss, _gout):
+        logits, label, data, row_lse, acc = ctx.saved_tensors
+        L = _l.load()
+        n, nc = logits.shape
+        g = gloss.contiguous().float().reshape(1)
+        dl = torch.empty_like(logits)
+        _l.check(L.urn_dense_ce_bwd(logits.data_ptr(), nc, label.data_ptr(), data.data_ptr(), _l.ptr(ctx.w), row_lse.data_ptr(),
+                                    acc.data_ptr(), g.data_ptr(), n, nc, dl.data_ptr(), _l.stream()), 'dense_ce_bwd')
+        return dl, None, None, None
+
+
+def segmentation_loss_event(seg, data, label, weight):
+    """seg (nc, *spatial) logits of one event (a channels-last view of the row matrix: no copy), data / label / weight
+    with one value per voxel -> (loss, [loss, accuracy])"""
+    nd = seg.dim() - 1
+    rows = seg.permute(*range(1, nd + 1), 0).reshape(-1, seg.shape[0])
+    n = rows.shape[0]
+    f = lambda t: None if t is None else t.reshape(-1).float().contiguous()
+    d, lab, w = f(data), f(label), f(weight)
+    assert d.numel() == n and lab.numel() == n and (w is None or w.numel() == n)
+    return DenseCEFunction.apply(rows, lab, d, w)

@@ -124,6 +124,9 @@ SIGNATURES = {
                                      c_void_p]),
     'urn_dense_bn_act_bwd_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                                             c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'urn_dense_ce_fwd': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_dense_ce_bwd': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p,
+                                 c_void_p]),
     'urn_dense_bn_bwd_finalize': (c_int, [c_void_p, c_int, c_int, c_i64, c_int, c_void_p, c_void_p]),
     'urn_dense_bn_act_bwd_apply': (c_int, [c_void_p] * 16 + [c_i64, c_int, c_void_p]),
     'urn_net_create': (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, c_int, ctypes.POINTER(c_void_p)]),

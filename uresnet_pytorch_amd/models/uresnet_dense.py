@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import dense_ops as D
+from ..utils import DeferredFloat
 
 
 def get_conv(is_3d):
@@ -160,6 +161,14 @@ class SegmentationLoss(torch.nn.modules.loss._Loss):
         if weight is not None:
             assert len(weight) == len(label)
         for i in range(len(data)):
+            if segmentation[i].is_cuda:
+                # one fused pass per event on the device; the accuracy stays there until it is looked at
+                from .. import dense_hip
+                loss_i, out = dense_hip.segmentation_loss_event(segmentation[i], data[i], label[i],
+                                                                None if weight is None else weight[i])
+                total_loss = loss_i if i == 0 else total_loss + loss_i
+                total_acc = out[1] if i == 0 else total_acc + out[1]
+                continue
             nonzero_idx = data[i] > 0.000001
             event_segmentation = segmentation[i].unsqueeze(0)
             event_label = label[i].squeeze(0).unsqueeze(0).long()
@@ -172,4 +181,6 @@ class SegmentationLoss(torch.nn.modules.loss._Loss):
             loss = (loss * nonzero_idx.float()).sum() / nnz.float()
             total_loss = total_loss + loss
             total_acc = total_acc + acc
+        if torch.is_tensor(total_acc) and total_acc.is_cuda:
+            return total_loss, DeferredFloat(total_acc)   # a float when used; no host sync between forward and backward
         return total_loss, float(total_acc)
