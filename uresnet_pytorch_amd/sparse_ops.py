@@ -98,6 +98,14 @@ class SparseGeometry:
                                                  self.parent[l].data_ptr(), self.off[l].data_ptr(), cptr + 4 * (l + 1),
                                                  self.chd[l].data_ptr(), cap, self.up[l].data_ptr(), cap, st),
                          'level_down_tables')
+        # The site counts are final here: their copy to (pinned) host memory is enqueued NOW, in front of the rulebook and
+        # pair-list launches, so that when sync() returns the queue still holds those (~50 us of work on the cfg3 event)
+        # and the host's first float-phase launches are not exposed (kernel trace before: 35 us idle at the blocking
+        # copy + 34 us until the next launch arrived, per step).
+        self._n_host = torch.empty(nl, dtype=torch.int32, pin_memory=True)
+        self._n_host.copy_(self.counts[:nl], non_blocking=True)
+        self._n_event = torch.cuda.Event()
+        self._n_event.record(torch.cuda.current_stream(dev))
         # the 27-offset tables of every level in one launch (the multi-level entry points take up to MAX_MULTI levels)
         if nl <= MAX_MULTI:
             _l.check(L.urn_rulebook_subm_multi(nl, PA(*[c.data_ptr() for c in self.coords]), PA(*[cptr + 4 * l for l in range(nl)]),
@@ -155,7 +163,11 @@ class SparseGeometry:
     def sync(self):
         """the one host synchronisation of the integer phase: per-level site counts"""
         if self.n is None:
-            self.n = self.counts.cpu().tolist()[:self.num_levels]
+            if os.environ.get('URN_LATE_COUNTS'):     # A/B: the blocking copy at the end of the integer phase
+                self.n = self.counts.cpu().tolist()[:self.num_levels]
+                return self
+            self._n_event.synchronize()
+            self.n = self._n_host.tolist()
         return self
 
     @property
