@@ -247,6 +247,14 @@ int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const float *xf_s
 int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy,
                              const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw,
                              void *stream);
+/* the same without atomics: every (row chunk, offset, channel tile) workgroup STORES its partial into `scratch`
+ * (urn_gconv_dw_2stage_scratch_bytes), a second launch adds the partials to dw in a fixed order -- bitwise reproducible.
+ * cin, cout multiples of 16. */
+int64_t urn_gconv_dw_2stage_scratch_bytes(int K, int64_t n_out, int cin, int cout);
+int64_t urn_gconv_dw_2stage_scratch_max(void);   /* enough for every shape (K <= 27): a few tens of MB */
+int urn_gconv_bwd_dw_2stage(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy,
+                            const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw, void *scratch,
+                            int64_t scratch_bytes, void *stream);
 /* column partials of a tensor whose producer cannot fuse them (the 1-channel stem) */
 int urn_bn_stats_partial(const float *x, int64_t n, int c, double *part, int *n_part, void *stream);
 int urn_bn_finalize_fwd(const double *part, int n_part, int64_t n, int c, int part_ld, double eps,

@@ -134,14 +134,15 @@ def test_pairs_subm_conv(dev, cin, cout):
     ref = orc.Geometry(c, f, S, 1)
     n = ref.n[0]
     p = geo.pairs['nbr'][0]
-    so.set_deterministic_dw(True)      # weight gradient on the two-stage pair-list kernel
-    try:
-        a = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
-        b = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
-    finally:
-        so.set_deterministic_dw(False)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), 'forward / input gradient not bitwise reproducible'
-    assert torch.equal(a[2], b[2]), 'weight gradient not bitwise reproducible (two-stage sum, no atomics)'
+    for kind in ('slabs', 'pairs'):    # both two-stage weight gradients: partial slabs of the table kernel, pair-list kernel
+        so.set_deterministic_dw(True, kind)
+        try:
+            a = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
+            b = run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
+        finally:
+            so.set_deterministic_dw(False)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), 'forward / input gradient not bitwise reproducible'
+        assert torch.equal(a[2], b[2]), 'weight gradient not bitwise reproducible (two-stage sum, no atomics): ' + kind
     # ... and the default weight-gradient kernel (dense table, fp32 atomics) against the oracle as well
     run_conv(dev, geo.nbr[0], ref.nbr[0], ref.nbr_inv[0], n, n, cin, cout, p, p, 1, geo.ld, True, cin * 100 + cout)
 
@@ -184,7 +185,7 @@ def test_conv_ops_on_cfg3_geometry(dev, cfg3, level):
     SubM3 P->P and 2P->P, NiN 2P->P, Convolution P->P', Deconvolution P'->P -- forward, dX, dW <= 1e-5 vs the oracle"""
     from uresnet_pytorch_amd import sparse_ops as so
     geo, ref = cfg3
-    so.set_deterministic_dw(level % 2 == 0)   # both weight-gradient kernels see the real geometry
+    so.set_deterministic_dw(level != 4, 'slabs' if level % 2 == 0 else 'pairs')   # all three weight-gradient kernels see the real geometry
     l, P = level, 16 * (level + 1)
     n = ref.n[l]
     p = geo.pairs['nbr'][l]

@@ -20,11 +20,11 @@ def run(n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-policies = [('tile only', 0, 0, 0, 6), ('all subm+strided', 999, 999, 0, 7), ('cin<=80', 80, 999, 0, 7), ('cin<=80,cout<=80', 80, 80, 0, 7), ('all, deterministic dW', 999, 999, 0, 7, 1)]
+policies = [('cin<=80 (default)', 80, 999, 0, 7), ('cin<=80, dW slabs', 80, 999, 0, 7, 'slabs'), ('cin<=80, dW pairs', 80, 999, 0, 7, 'pairs')]
 res = {p[0]: [] for p in policies}
 for rnd in range(3):
     for name, mi, mo, nin, k, *rest in policies:
-        so.set_deterministic_dw(bool(rest[0]) if rest else False)
+        so.set_deterministic_dw(bool(rest), rest[0] if rest else 'slabs')
         L.urn_set_option(b'gconv_kernel', k); L.urn_set_option(b'pairs_max_cin', mi); L.urn_set_option(b'pairs_max_cout', mo); L.urn_set_option(b'pairs_nin', nin)
         res[name].append(run())
 for name, *_ in policies:

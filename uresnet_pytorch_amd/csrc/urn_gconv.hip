@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
                                                    const float *__restrict__ xf_shift, const float *__restrict__ dy,
                                                    const int *__restrict__ tbl, long ld, long n_out, int cin,
                                                    int cout, long chunk, int n_ci_tiles,
-                                                   float *__restrict__ dw, long ld_dy)
+                                                   float *__restrict__ dw, long ld_dy, float *__restrict__ slab)
 {
     __shared__ int s_in[DW2_LIST], s_out[DW2_LIST];
     __shared__ int s_cnt[16];
@@ -414,17 +414,41 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
             if (b + 1 < nbatch) step(b + 1, I1());
         }
     }
-    // accumulate this block's partial into dw[o][ci][co]; C layout: col = lane&15, row = q*4+i
+    // accumulate this block's partial into dw[o][ci][co]; C layout: col = lane&15, row = q*4+i.  Two-stage mode (slab):
+    // the partial is STORED into slab[part][o][ci][co], part = (row chunk, wave-partial of a split batch) -- every element
+    // of a part is written by exactly one wave of the grid; k_dw2_reduce adds the parts in a fixed order (no atomics:
+    // bitwise reproducible)
+    const long wn = (long)gridDim.y * cin * cout;
+    float *dst = slab ? slab + ((long)blockIdx.x * WPB + (KT > 32 ? wave / nblk : 0)) * wn : dw;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         if (KT > 32 || wave + 4 * s < nblk) {   // split batches: every wave holds a partial of its block
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ci = ci0 + mi_[s] * 16 + q * 4 + i, co = co0 + ni_[s] * 16 + m;
-                atomicAdd(&dw[((long)o * cin + ci) * cout + co], acc[s][i]);
+                if (slab) dst[((long)o * cin + ci) * cout + co] = acc[s][i];
+                else atomicAdd(&dst[((long)o * cin + ci) * cout + co], acc[s][i]);
             }
         }
     }
+}
+
+// dw[e] += slab[0][e] + slab[1][e] + ... (fixed order), eight independent loads in flight per thread
+__global__ void k_dw2_reduce(const float *__restrict__ slab, int P, long n, float *__restrict__ dw)
+{
+    const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= n) return;             // n = K * cin * cout with cin, cout multiples of 16
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= P; s += 8) {
+        f32x4 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = *(const f32x4 *)(slab + (long)(s + k) * n + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += p[k];
+    }
+    for (; s < P; ++s) v += *(const f32x4 *)(slab + (long)s * n + e);
+    *(f32x4 *)(dw + e) += v;
 }
 
 // VALU weight gradient for channel counts that are not multiples of 16 (the 1-channel stem).
@@ -485,9 +509,63 @@ extern "C" int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const 
     return urn_gconv_bwd_dw_strided(x, xf_scale, xf_shift, dy, cout, tbl, ld, K, n_out, cin, cout, dw, stream);
 }
 
+// launch plan of k_gconv_dw2: row chunks, rows per chunk, partials per chunk (the wave-partials of the split-batch variants)
+static void dw2_plan(int K, int64_t n_out, int cin, int cout, int &chunks, long &chunk, int &wpb)
+{
+    const int n_ci_tiles = urn_cdiv(cin, DW_MAXI * 16), n_co_tiles = urn_cdiv(cout, DW_MAXN * 16);
+    // aim for ~2048 blocks, chunks of at least 256 rows (multiple of 256)
+    // (the tuned target holds up to ~100k rows; launches over larger levels own more of the chip: 4 events per GPU
+    // measured 9.5 ms per step with 2048 against 10.0 with 1152)
+    const int dw_target = n_out >= 150000 && g_dw_blocks < 2048 ? 2048 : g_dw_blocks;
+    chunks = dw_target / (K * n_ci_tiles * n_co_tiles);
+    if (chunks < 1) chunks = 1;
+    chunk = (n_out + chunks - 1) / chunks;
+    if (chunk < 256) chunk = 256;
+    chunk = ((chunk + 255) / 256) * 256;
+    chunks = (int)((n_out + chunk - 1) / chunk);
+    const int ci_w = cin < DW_MAXI * 16 ? cin : DW_MAXI * 16, co_w = cout < DW_MAXN * 16 ? cout : DW_MAXN * 16;
+    const int nblk_max = (ci_w / 16) * (co_w / 16);
+    const bool split = g_dw_split == 2 || (g_dw_split == 1 && n_out >= 131072);
+    wpb = (nblk_max == 1 && split) ? 4 : ((nblk_max == 2 && split) ? 2 : 1);
+}
+
+static int dw_launch(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy, const int32_t *tbl,
+                     int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw, float *slab, int64_t slab_bytes, void *stream);
+
+extern "C" int64_t urn_gconv_dw_2stage_scratch_bytes(int K, int64_t n_out, int cin, int cout)
+{
+    if (K <= 0 || n_out < 0 || cin <= 0 || cout <= 0 || cin % 16 || cout % 16) return -1;
+    int chunks, wpb; long chunk;
+    dw2_plan(K, n_out > 0 ? n_out : 1, cin, cout, chunks, chunk, wpb);
+    // (the plan depends on the options dw_blocks / dw_split: sized for the largest split either way)
+    return (int64_t)chunks * 4 * K * cin * cout * 4;
+}
+
+// upper bound over every shape: parts x K x cin x cout = workgroups x tile floats x wave-partials; the plan launches at most
+// max(dw_blocks, 2048) + K * tiles workgroups of at most DW_MAXI * 16 x DW_MAXN * 16 floats (x 4 only for 16 x 16 tiles)
+extern "C" int64_t urn_gconv_dw_2stage_scratch_max(void)
+{
+    const int64_t wgs = (g_dw_blocks > 2048 ? g_dw_blocks : 2048) + 27 * 16;
+    return wgs * (DW_MAXI * 16) * (DW_MAXN * 16) * 4;
+}
+
+extern "C" int urn_gconv_bwd_dw_2stage(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy,
+                                       const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw,
+                                       void *scratch, int64_t scratch_bytes, void *stream)
+{
+    URN_CHECK_ARG(scratch && cin % 16 == 0 && cout % 16 == 0, "two-stage weight gradient: scratch and channel counts that are multiples of 16");
+    return dw_launch(x, xf_scale, xf_shift, dy, ld_dy, tbl, ld, K, n_out, cin, cout, dw, (float *)scratch, scratch_bytes, stream);
+}
+
 extern "C" int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, const float *xf_shift, const float *dy,
                                         int64_t ld_dy, const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin,
                                         int cout, float *dw, void *stream)
+{
+    return dw_launch(x, xf_scale, xf_shift, dy, ld_dy, tbl, ld, K, n_out, cin, cout, dw, nullptr, 0, stream);
+}
+
+static int dw_launch(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy, const int32_t *tbl,
+                     int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw, float *slab, int64_t slab_bytes, void *stream)
 {
     URN_CHECK_ARG(ld_dy >= cout && ld_dy % 4 == 0, "ld_dy smaller than the row or not a multiple of 4");
     if (n_out <= 0) return URN_OK;
@@ -510,16 +588,13 @@ extern "C" int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, c
         return URN_OK;
     }
     const int n_ci_tiles = urn_cdiv(cin, DW_MAXI * 16), n_co_tiles = urn_cdiv(cout, DW_MAXN * 16);
-    // aim for ~2048 blocks, chunks of at least 256 rows (multiple of 256)
-    // (the tuned target holds up to ~100k rows; launches over larger levels own more of the chip: 4 events per GPU
-    // measured 9.5 ms per step with 2048 against 10.0 with 1152)
-    const int dw_target = n_out >= 150000 && g_dw_blocks < 2048 ? 2048 : g_dw_blocks;
-    int chunks = dw_target / (K * n_ci_tiles * n_co_tiles);
-    if (chunks < 1) chunks = 1;
-    long chunk = (n_out + chunks - 1) / chunks;
-    if (chunk < 256) chunk = 256;
-    chunk = ((chunk + 255) / 256) * 256;
-    chunks = (int)((n_out + chunk - 1) / chunk);
+    int chunks, wpb; long chunk;
+    dw2_plan(K, n_out, cin, cout, chunks, chunk, wpb);
+    const long wn = (long)K * cin * cout;
+    if (slab && (g_dw_kernel != 2 || slab_bytes < (int64_t)chunks * wpb * wn * 4)) {
+        urn_set_error("urn_gconv_bwd_dw_2stage: scratch smaller than urn_gconv_dw_2stage_scratch_bytes");
+        return URN_EINVAL;
+    }
     const bool prof = urn_prof_on();
     if (prof) urn_prof_begin(URN_PROF_DW, st);
     const dim3 grid(chunks, K, n_ci_tiles * n_co_tiles);
@@ -533,11 +608,11 @@ extern "C" int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, c
 #define URN_DW2P(Sv, XFv, KTv)                                                                                                       \
         do {                                                                                                                         \
             if (prec == 1) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 1>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, \
-                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy);              \
+                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab);        \
             else if (prec == 2) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 2>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, \
-                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy);    \
+                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab); \
             else hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 0>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
-                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy);                                  \
+                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab);                            \
         } while (0)
 #define URN_DW2K(Sv, KTv)                                                                                                            \
         if (xf_scale) URN_DW2P(Sv, 1, KTv);                                                                                          \
@@ -558,6 +633,7 @@ extern "C" int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, c
         hipLaunchKernelGGL(k_gconv_dw, grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld,
                            (long)n_out, cin, cout, chunk, n_ci_tiles, dw);
     }
+    if (slab) hipLaunchKernelGGL(k_dw2_reduce, dim3(urn_cdiv(wn / 4, 256)), dim3(256), 0, st, (const float *)slab, chunks * wpb, wn, dw);
     if (prof) urn_prof_end(st);
     URN_LAUNCH_CHECK();
     return URN_OK;

@@ -18,6 +18,7 @@
 
 int g_dw_group = 1;   // weight gradients per fork to the side stream (urn_set_option "dw_group"); measured: 1: 3.61 ms, 2: 3.66, 4: 3.64, 8: 3.74, 16: 3.85
 
+int g_dw_2stage = 0;       // weight gradients of the table kernel as per-chunk partial slabs + a fixed-order reduce instead of fp32 atomics (urn_set_option "dw_2stage")
 int g_dw_pairs = 0;        // weight gradients on the two-stage pair-list kernel (bitwise reproducible) instead of the atomics kernel (urn_set_option "dw_pairs")
 int g_net_side_probe = 4;   // candidate side streams tried by an executor's first backward (urn_set_option "net_side_probe"; 0/1 = keep the first)
 int g_net_side_verbose = 0;
@@ -147,6 +148,8 @@ struct urn_net {
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
     bool side_used = false;
+    void *dw2_shared = nullptr;        // partial slabs of the two-stage weight gradients (dw_scratch), one region per backward
+    hipStream_t dw2_stream = nullptr;  // the stream they all run on
     bool side_probed = false;
     bool pairs_armed = false;            // urn_net_set_pairs was called for the coming forward
     // keep the fastest of g_net_side_probe candidate side streams for this executor's main stream (see probe_pair)
@@ -236,7 +239,14 @@ struct urn_net {
     void *dw_scratch(const ConvP &c, const int32_t *tbl_f, int64_t n_out)
     {
         const int32_t *list; int tile;
-        if (!g_dw_pairs) return nullptr;   // default: the dense-table kernel (fp32 atomics), 1.5-2.5x faster per launch
+        if (!g_dw_pairs) {
+            // the dense-table kernel: partial slabs + fixed-order reduce (dw_2stage), or fp32 atomics
+            // ONE slab region for all of them (a launch writes at most ~ workgroups x tile floats whatever the level size,
+            // and the weight gradients of a backward pass run one after the other on one stream)
+            if (!g_dw_2stage || c.cin % 16 || c.cout % 16) return nullptr;
+            if (!dw2_shared) dw2_shared = arena.alloc_bytes((size_t)urn_gconv_dw_2stage_scratch_max());
+            return dw2_shared;
+        }
         geo.pairs_of(tbl_f, list, tile);
         if (arena.dry) tile = 64;   // workspace sizing: the lists arrive with the real forward (the size does not depend on the tile)
         if (!tile || c.cin % 16 || c.cout % 16) return nullptr;
@@ -247,6 +257,14 @@ struct urn_net {
     {
         const int32_t *list; int tile;
         geo.pairs_of(tbl_f, list, tile);
+        if (scratch && !g_dw_pairs) {
+            if (!dw2_stream) dw2_stream = ws;
+            if (dw2_stream == ws)      // (a launch that could not fork onto the side stream must not share the slab: atomics)
+                return urn_gconv_bwd_dw_2stage(c.x, xf ? xf->scale : nullptr, xf ? xf->shift : nullptr, dy, ld_dy > 0 ? ld_dy : c.cout,
+                                               tbl_f, geo.ld, c.K, n_out, c.cin, c.cout, grads + c.w, scratch,
+                                               urn_gconv_dw_2stage_scratch_max(), ws);
+            scratch = nullptr;
+        }
         if (scratch && tile)
             return urn_gconv_bwd_dw_pairs(c.x, 0, xf ? xf->scale : nullptr, xf ? xf->shift : nullptr, dy, ld_dy, list, tile, c.K,
                                           n_out, c.cin, c.cout, grads + c.w, scratch,
@@ -944,6 +962,7 @@ static void run_backward(urn_net *net, const float *d_rows)
 {
     // OutputLayer backward: scatter-add input-row gradients onto sites
     const int64_t n0 = net->geo.n[0];
+    net->dw2_shared = nullptr; net->dw2_stream = nullptr;
     float *d = net->arena.f32(n0 * net->m);
     if (net->live()) {
         net->check(hipMemsetAsync(d, 0, (size_t)n0 * net->m * 4, net->st) == hipSuccess ? URN_OK : URN_EHIP);

@@ -101,6 +101,10 @@ SIGNATURES = {
                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_gconv_bwd_dw_strided': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_i64,
                                          c_int, c_int, c_void_p, c_void_p]),
+    'urn_gconv_dw_2stage_scratch_bytes': (c_i64, [c_int, c_i64, c_int, c_int]),
+    'urn_gconv_dw_2stage_scratch_max': (c_i64, []),
+    'urn_gconv_bwd_dw_2stage': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_i64,
+                                        c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
     'urn_adam_flat': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_double, c_double, c_double, c_double,
                               c_double, c_i64, c_void_p]),
     'urn_rows_gather': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),

@@ -203,16 +203,21 @@ def input_features(geo, feats):
 
 
 IDENT_PAIRS = (None, 64)     # the identity table of a 1x1 convolution needs no list
-# Weight gradients of the per-layer path on the two-stage pair-list kernel (bitwise reproducible) instead of the dense-table
-# kernel that adds partial tiles with fp32 atomics (1.5-2.5x faster per launch, last bits depend on the arrival order).
+# Weight gradients without fp32 atomics (bitwise reproducible): False = the dense-table kernel adding its partial tiles with
+# atomics (last bits depend on the arrival order); 'slabs' = the same kernel storing the partials of every (row chunk,
+# offset, channel tile) workgroup, added by a second launch in a fixed order; 'pairs' = the two-stage kernel on the
+# compacted rule lists (1.5-2.5x slower per launch).
 DETERMINISTIC_DW = False
 
 
-def set_deterministic_dw(on):
-    """Both routes: the per-layer autograd path and the executor (urn_set_option("dw_pairs"))."""
+def set_deterministic_dw(on, kind='slabs'):
+    """Both routes: the per-layer autograd path and the executor (urn_set_option "dw_2stage" / "dw_pairs")."""
     global DETERMINISTIC_DW
-    DETERMINISTIC_DW = bool(on)
-    _l.load().urn_set_option(b'dw_pairs', int(bool(on)))
+    assert kind in ('slabs', 'pairs')
+    DETERMINISTIC_DW = kind if on else False
+    L = _l.load()
+    L.urn_set_option(b'dw_pairs', int(bool(on) and kind == 'pairs'))
+    L.urn_set_option(b'dw_2stage', int(bool(on) and kind == 'slabs'))
 
 
 def _gconv(x, wt, tbl, ld, K, flip, n_out, cin, cout, res=None, pairs=None):
@@ -273,7 +278,12 @@ class GConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight)
             pf = ctx.pairs_f
-            if DETERMINISTIC_DW and pf is not None and cin % 16 == 0 and cout % 16 == 0:
+            if DETERMINISTIC_DW == 'slabs' and cin % 16 == 0 and cout % 16 == 0:
+                sb = L.urn_gconv_dw_2stage_scratch_bytes(K, n_out, cin, cout)
+                scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+                _l.check(L.urn_gconv_bwd_dw_2stage(_l.ptr(x), None, None, _l.ptr(dy), cout, tbl_f.data_ptr(), ld, K, n_out, cin, cout,
+                                                   dw.data_ptr(), scratch.data_ptr(), sb, _l.stream()), 'gconv_bwd_dw_2stage')
+            elif DETERMINISTIC_DW == 'pairs' and pf is not None and cin % 16 == 0 and cout % 16 == 0:
                 # two-stage sum over the compacted rule list: no atomics, bitwise reproducible
                 sb = L.urn_gconv_dw_pairs_scratch_bytes(n_out, pf[1], K, cin, cout)
                 scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)

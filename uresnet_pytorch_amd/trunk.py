@@ -189,7 +189,7 @@ class TrunkExecutor:
         """The workspace need is linear in the level sizes and the row count (every allocation is rows x channels,
         rounded up to 256 B): one dry run per unit vector, cached, replaces a dry run of the whole graph per step --
         that call sat between the level-count synchronisation and the first kernel of the forward pass."""
-        key = (num_levels, int(with_backward), bool(so.DETERMINISTIC_DW))   # (the two-stage weight gradient needs its partial slabs)
+        key = (num_levels, int(with_backward), so.DETERMINISTIC_DW)   # (the two-stage weight gradient needs its partial slabs)
         if key not in self._ws_coef:
             L = _l.load()
             U = 1 << 16
