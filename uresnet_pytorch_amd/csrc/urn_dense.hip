@@ -287,8 +287,13 @@ __global__ __launch_bounds__(512) void k_dense_conv(DenseArgs g)
 // ~1450 scalar and ~1900 vector instructions per wave on loop bookkeeping for 54 MFMAs at 16 channels -- the scalar unit of
 // a CU alone was busy for half of the kernel's time (PMC: SQ_INSTS_SALU).  REV: tap j reads box offset 2 - j (the input
 // gradient's e = -j) instead of j.  Weight tiles are staged one z-slice (9 taps) at a time.
+// Registers decide how many workgroups share a CU (a workgroup is 2 waves per SIMD).  Without a bound hipcc took up to 256
+// VGPRs for the wide chunks (one resident workgroup, nothing to hide its barriers behind): the launch bounds ask for 4 waves
+// per SIMD (<= 128 VGPRs, 2 workgroups per CU) where the LDS image allows two workgroups.  Measured at 128^3 x 16 -> 16,
+// bf16: 131 us at 94 VGPRs / 2 workgroups; forced to 80 VGPRs (3 workgroups) 174 us, to 64 (4 workgroups) slower still --
+// the spills cost more than the occupancy gives.
 template <int PREC, int KC, int NCB, int REV>
-__global__ __launch_bounds__(512) void k_dense_conv3(DenseArgs g)
+__global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dense_conv3(DenseArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int ES = PREC ? 2 : 4, CH = 16 * KC, ROWB = CH * ES + 16;
@@ -326,32 +331,54 @@ __global__ __launch_bounds__(512) void k_dense_conv3(DenseArgs g)
     const int jz_lo = g.zt == 3 ? zti : 0, jz_hi = g.zt == 3 ? zti + 1 : 3;
     for (int ch0 = chunk_lo * CH; ch0 < chunk_hi * CH; ch0 += CH) {
         __syncthreads();
-        // box: one (bz, by) row per wave and pass
-        for (int rowi = wave; rowi < BZ * BY; rowi += 8) {
-            const int bz = rowi / BY, by = rowi - bz * BY;
-            int iz = iz0 + bz, iy = iy0 + by;
-            bool okr = true;
-            if (g.mode == 0) { iz = min(max(iz, 0), g.In[0] - 1); iy = min(max(iy, 0), g.In[1] - 1); }
-            else { okr = iz >= 0 && iz < g.In[0] && iy >= 0 && iy < g.In[1]; if (!okr) { iz = 0; iy = 0; } }
-            const float *src_row = g.x + (in_rows_b + ((long)iz * g.In[1] + iy) * g.In[2]) * g.ldx + ch0;
-            unsigned char *dst_row = s_box + rowi * BX * ROWB;
+        // box: 36 (bz, by) rows x 18 voxels x PER 16-byte pieces, dealt flat over the 512 threads; every division below is by
+        // a compile-time constant.  ALL loads of a thread are issued before the first conversion: one round trip per
+        // chunk (the row-per-wave loop this replaces waited for each row's loads before it asked for the next row: five
+        // dependent round trips per workgroup, 155 us for 128^3 x 16 -> 16 where the HBM traffic needs 45).
+        {
+            constexpr int ROW_E = BX * PER, TOT_E = BZ * BY * ROW_E, NIT = (TOT_E + 511) / 512;
+            constexpr int HALF = NIT > 6 ? 6 : NIT;        // six 16-byte loads in flight per thread and batch (registers)
 #pragma unroll
-            for (int it = 0; it < (BX * PER + 63) / 64; ++it) {
-                const int e = it * 64 + lane;
-                if (e < BX * PER) {
-                    const int bx = e >> PER_LOG, k4 = e & (PER - 1);
-                    int ix = ix0 + bx;
-                    bool ok = okr;
-                    if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
-                    else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
-                    f32x4 val = *(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4);
-                    if (!ok) val = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if constexpr (PREC) {
-                        uint2 pk;
-                        pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
-                        *(uint2 *)(dst_row + bx * ROWB + 8 * k4) = pk;
-                    } else {
-                        *(f32x4 *)(dst_row + bx * ROWB + 16 * k4) = val;
+            for (int h0 = 0; h0 < NIT; h0 += HALF) {
+                f32x4 val[HALF];
+                bool okv[HALF];
+#pragma unroll
+                for (int it = 0; it < HALF; ++it) {
+                    const int f = (h0 + it) * 512 + tid;
+                    okv[it] = false;
+                    val[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (h0 + it < NIT && f < TOT_E) {
+                        const int rowi = f / ROW_E, e = f - rowi * ROW_E;
+                        const int bz = rowi / BY, by = rowi - bz * BY;
+                        const int bx = e >> PER_LOG, k4 = e & (PER - 1);
+                        int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+                        bool ok = true;
+                        if (g.mode == 0) {
+                            iz = min(max(iz, 0), g.In[0] - 1); iy = min(max(iy, 0), g.In[1] - 1); ix = min(max(ix, 0), g.In[2] - 1);
+                        } else {
+                            ok = iz >= 0 && iz < g.In[0] && iy >= 0 && iy < g.In[1] && ix >= 0 && ix < g.In[2];
+                            if (!ok) { iz = 0; iy = 0; ix = 0; }
+                        }
+                        okv[it] = ok;
+                        val[it] = *(const f32x4 *)(g.x + (in_rows_b + ((long)iz * g.In[1] + iy) * g.In[2] + ix) * g.ldx + ch0 + 4 * k4);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < HALF; ++it) {
+                    const int f = (h0 + it) * 512 + tid;
+                    if (h0 + it < NIT && f < TOT_E) {
+                        const int rowi = f / ROW_E, e = f - rowi * ROW_E;
+                        const int bx = e >> PER_LOG, k4 = e & (PER - 1);
+                        f32x4 v = val[it];
+                        if (!okv[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        unsigned char *dst = s_box + (rowi * BX + bx) * ROWB;
+                        if constexpr (PREC) {
+                            uint2 pk;
+                            pk.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); pk.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                            *(uint2 *)(dst + 8 * k4) = pk;
+                        } else {
+                            *(f32x4 *)(dst + 16 * k4) = v;
+                        }
                     }
                 }
             }

@@ -254,6 +254,7 @@ struct Pick { int mb, nb; };
 // before the column tile is widened
 int g_opt_precision = 0;   // default MFMA operand precision of the gather convolutions: 0 fp32, 1 bf16, 2 fp16
 extern int g_dw_pairs;
+extern int g_pairs_deep;
 extern int g_dw_2stage;
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
@@ -280,6 +281,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "pairs_nc")) { g_pairs_nc = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_cbg")) { g_pairs_cbg = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_wgs")) { g_pairs_wgs = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_deep")) { g_pairs_deep = value != 0; return URN_OK; }
     if (!strcmp(key, "dw_pairs")) { g_dw_pairs = value != 0; return URN_OK; }
     if (!strcmp(key, "dw_2stage")) { g_dw_2stage = value != 0; return URN_OK; }
     if (!strcmp(key, "dwp_cap")) { g_dwp_cap = value >= 1 && value <= 5 ? (int)value : 2; return URN_OK; }

@@ -38,7 +38,7 @@ struct GArgs {
     // compacted rule lists (urn_gconv_pairs.hip): list of the table (NULL with p_tile != 0 = identity table of a 1x1 conv),
     // rows per tile (64 / 128), split of a tile's block list over waves, columns per workgroup
     const int *pairs;
-    int p_tile, p_split, p_cw;
+    int p_tile, p_split, p_cw, p_deep;
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };
 

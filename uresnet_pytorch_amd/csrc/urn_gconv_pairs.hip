@@ -204,6 +204,68 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + (long)(16 * c) * cin + 16 * j);
     };
 
+    if (nch == 1 && g.p_deep) {
+        // One channel chunk (cin = 16 KC; enabled by the launcher for KC == 1): THREE row-register sets rotate, so
+        // that the rows of blocks b + 1 and b + 2 are in flight while block b is multiplied (one set in flight left a wave
+        // at the unpipelined gather rate: 3 wave-loads/us against 20 with four in flight, tools/ubench/gather_rate.hip).
+        // The loop is unrolled by three so that no register set is ever copied (a copy of a register with a pending load
+        // waits for it); the pair words arrive in triples, two triples ahead of their use.
+        if (b0 < b1) {
+            f32x4 A0[KC], A1[KC], A2[KC];
+            int pP[3], tP[3], pQ[3], tQ[3], pR[3], tR[3];
+            auto idx3 = [&](int b, int (&pv)[3], int (&tv)[3]) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) load_idx(b + k < b1 ? b + k : b1 - 1, pv[k], tv[k]);
+            };
+            idx3(b0, pP, tP);
+            idx3(b0 + 3, pQ, tQ);
+            load_a(A0, pP[0], 0);
+            load_a(A1, pP[1], 0);
+            int w_key = -1;
+            // one block: slab rows of pair word pv / offset tv from `use`; the rows of the block two ahead go into `ld`
+            auto step = [&](f32x4 (&use)[KC], f32x4 (&ld)[KC], int pv, int tv, int pv_ld) {
+                const int t_c = __builtin_amdgcn_readfirstlane(tv);
+                float *dptr = slab + (long)((unsigned)pv >> 24) * LDW + 4 * q;
+                f32x4 old[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) old[c] = *(const f32x4 *)(dptr + 16 * c);
+                if (t_c != w_key) { load_w(w_cur, t_c, 0); w_key = t_c; }   // wave-uniform; before the younger row loads
+                load_a(ld, pv_ld, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (XF != 0) {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const f32x4 sc = *(const f32x4 *)(s_xf + 16 * j + 4 * q);
+                        const f32x4 sh = *(const f32x4 *)(s_xf + cin + 16 * j + 4 * q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) use[j][k] = fmaxf(fmaf(use[j][k], sc[k], sh[k]), 0.f);
+                    }
+                }
+                f32x4 acc[NC], acc2[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int j = 0; j < KC; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], use[j][tt], acc2[c]);
+                            else acc[c] = MFMA16(w_cur[j][c][tt], use[j][tt], acc[c]);
+                        }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = old[c] + (acc[c] + acc2[c]);
+            };
+            for (int b = b0; b < b1; b += 3) {
+                idx3(b + 6, pR, tR);
+                step(A0, A2, pP[0], tP[0], pP[2]);
+                if (b + 1 < b1) step(A1, A0, pP[1], tP[1], pQ[0]);
+                if (b + 2 < b1) step(A2, A1, pP[2], tP[2], pQ[1]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { pP[k] = pQ[k]; tP[k] = tQ[k]; pQ[k] = pR[k]; tQ[k] = tR[k]; }
+            }
+        }
+    } else
     // Steps s = (block, channel chunk).  The gathered rows of step s + 1 are requested before the MFMAs of step s and the
     // pair words three blocks ahead.  The weight fragments stay in registers while the offset (and chunk) does not
     // change; when it does they are requested BEFORE the next step's rows, so that waiting for them (s_waitcnt vmcnt(N)
@@ -328,6 +390,7 @@ int g_pairs_waves = 4096;    // a launch is split G ways until it has about this
 int g_pairs_nc = 0;          // force the column blocks per wave (urn_set_option "pairs_nc"), 0 = automatic
 int g_pairs_split = 0;
 int g_pairs_wgs = 512;       // a workgroup takes several column groups only while the launch keeps this many workgroups ("pairs_wgs")
+int g_pairs_deep = 1;        // three rotating row-register sets for 16-channel inputs (urn_set_option "pairs_deep")
 int g_pairs_cbg = 0;          // most column groups per workgroup (urn_set_option "pairs_cbg"), 0 = as many as fit       // force G (urn_set_option "pairs_split"), 0 = automatic
 
 template <int KC, int NC>
@@ -372,7 +435,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < g_pairs_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= 65536) ++G;
     if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= 65536) G = g_pairs_split;
     if (lds_bytes(G) > 65536) return 0;
-    a.p_split = G; a.p_cw = cw;
+    a.p_split = G; a.p_cw = cw; a.p_deep = g_pairs_deep && kc == 1;   // measured: 16 -> 16 12 -> 11 us; wider rows 5-15 % slower (registers)
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
     const size_t lds = lds_bytes(G);
 #define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs2<KCv, NCv>(a, grid, block, lds, st); return (int)ntiles; }
