@@ -204,7 +204,9 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + (long)(16 * c) * cin + 16 * j);
     };
 
-    if (nch == 1 && g.p_deep) {
+    bool deep_path = false;
+    if constexpr (KC == 1) deep_path = nch == 1 && g.p_deep;   // compiled for 16-channel inputs only: the other shapes keep their registers
+    if constexpr (KC == 1) if (deep_path) {
         // One channel chunk (cin = 16 KC; enabled by the launcher for KC == 1): THREE row-register sets rotate, so
         // that the rows of blocks b + 1 and b + 2 are in flight while block b is multiplied (one set in flight left a wave
         // at the unpipelined gather rate: 3 wave-loads/us against 20 with four in flight, tools/ubench/gather_rate.hip).
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
                 for (int k = 0; k < 3; ++k) { pP[k] = pQ[k]; tP[k] = tQ[k]; pQ[k] = pR[k]; tQ[k] = tR[k]; }
             }
         }
-    } else
+    }
+    if (!deep_path)
     // Steps s = (block, channel chunk).  The gathered rows of step s + 1 are requested before the MFMAs of step s and the
     // pair words three blocks ahead.  The weight fragments stay in registers while the offset (and chunk) does not
     // change; when it does they are requested BEFORE the next step's rows, so that waiting for them (s_waitcnt vmcnt(N)

@@ -170,6 +170,11 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        # developer switch for A/B runs of whole programs: URN_OPTIONS="key=value,key=value" -> urn_set_option
+        for kv in filter(None, os.environ.get('URN_OPTIONS', '').split(',')):
+            k, v = kv.split('=')
+            if L.urn_set_option(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError('URN_OPTIONS: unknown option %r' % k)
     return _lib
 
 
