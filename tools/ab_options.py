@@ -1,0 +1,37 @@
+"""A/B of urn_set_option settings on the cfg3 training step IN ONE PROCESS (box-to-box differences of a few percent hide
+1-2 % effects): python tools/ab_options.py "pairs_waves=4096" "pairs_waves=2560" "pairs_waves=2560,dw_blocks=640" ...
+Each argument is one policy (comma-separated key=value; the first is the baseline whose keys are restored between
+policies).  Rounds of 20 steps per policy, interleaved, 5 rounds; prints min / median per policy."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from types import SimpleNamespace
+import numpy as np, torch
+from uresnet_pytorch_amd import lib as L_, parallel
+from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
+from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
+L = L_.load(); dev = torch.device('cuda:0')
+DEFAULTS = {'pairs_waves': 2560, 'pairs_wgs': 512, 'dw_blocks': 768, 'pairs_deep': 1, 'pairs_max_cin': 80, 'pairs_max_cout': 999,
+            'pairs_nc': 0, 'pairs_split': 0, 'pairs_cbg': 0, 'dw_split': 2, 'dw_2stage': 0}
+flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=5, SPATIAL_SIZE=512, NUM_CLASS=5)
+torch.manual_seed(0)
+model = SparseUResNet(flags).to(dev).train(); crit = SparseSegmentationLoss(flags)
+blob = make_sparse_blob([0], 512, 50000)
+data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
+grads = parallel.FlatGradients(model); opt = parallel.FlatAdam(grads, lr=1e-3)
+def step():
+    grads.zero(); out = model(data); loss, _ = crit(out, [data], [label], None); loss.backward(); grads.all_reduce(); opt.step()
+def run(n=20):
+    for _ in range(3): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): step()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+policies = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in a.split(',') if kv) for a in sys.argv[1:]] or [{}]
+res = [[] for _ in policies]
+for rnd in range(5):
+    for i, pol in enumerate(policies):
+        for k, v in DEFAULTS.items(): L.urn_set_option(k.encode(), v)
+        for k, v in pol.items():
+            assert L.urn_set_option(k.encode(), v) == 0, k
+        res[i].append(run())
+for a, r in zip(sys.argv[1:], res):
+    print('%-44s min %.3f  median %.3f  all %s' % (a, min(r), float(np.median(r)), ' '.join('%.3f' % v for v in r)), flush=True)

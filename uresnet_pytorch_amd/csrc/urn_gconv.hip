@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw_small(const float *__restrict_
 extern int g_opt_precision;
 int g_dw_split = 2;       // split-batch variants of k_gconv_dw2 for one- and two-block tiles: 0 never, 1 automatic, 2 always (urn_set_option "dw_split")
 int g_dw_kernel = 2;      // 2 = k_gconv_dw2 (default), 1 = k_gconv_dw (urn_set_option "dw_kernel")
-int g_dw_blocks = 1152;   // target number of workgroups of the weight-gradient kernel (urn_set_option "dw_blocks"); alone 2048 is the optimum, beside the dX chain (split-batch variants) 1024-1280: 3.44 ms per cfg3 step against 3.50 at 1536 and 3.57 at 2048
+int g_dw_blocks = 768;    // target number of workgroups of the weight-gradient kernel (urn_set_option "dw_blocks"); alone 2048 is the optimum; beside the dX chain fewer are better (round 1: 3.44 ms per cfg3 step at 1024-1280 against 3.50 at 1536 and 3.57 at 2048; round 2, pair-list dX kernels: 3.20 at 768 = three per CU, 3.22 at 640, 3.23 at 896, 3.24 at 1024-1152, 3.33 at 512, 4.07 at 256 where the side stream becomes the critical path)
 
 extern "C" int urn_gconv_bwd_dw(const float *x, const float *dy, const int32_t *tbl, int64_t ld, int K,
                                 int64_t n_out, int cin, int cout, float *dw, void *stream)

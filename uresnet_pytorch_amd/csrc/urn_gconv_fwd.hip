@@ -303,7 +303,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "net_side_probe")) { g_net_side_probe = (int)value; return URN_OK; }
     if (!strcmp(key, "net_side_verbose")) { g_net_side_verbose = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_group")) { g_dw_group = value > 0 ? (int)value : 1; return URN_OK; }
-    if (!strcmp(key, "dw_blocks")) { g_dw_blocks = value > 0 ? (int)value : 1152; return URN_OK; }
+    if (!strcmp(key, "dw_blocks")) { g_dw_blocks = value > 0 ? (int)value : 768; return URN_OK; }
     urn_set_error("urn_set_option: unknown key %s", key);
     return URN_EINVAL;
 }

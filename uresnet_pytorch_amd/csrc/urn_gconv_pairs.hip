@@ -389,7 +389,7 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
     }
 }
 
-int g_pairs_waves = 4096;    // a launch is split G ways until it has about this many waves (urn_set_option "pairs_waves")
+int g_pairs_waves = 2560;    // a launch is split G ways until it has about this many waves (urn_set_option "pairs_waves"): alone more is faster (4096+), beside the weight gradients of the training step fewer are (A/B in one process, tools/ab_options.py: 3.21 ms per step at 4096, 3.12 at 3072, 3.06 at 2560, 3.09 at 2304, 3.12 at 2048, 3.19 at 1536)
 int g_pairs_nc = 0;          // force the column blocks per wave (urn_set_option "pairs_nc"), 0 = automatic
 int g_pairs_split = 0;
 int g_pairs_wgs = 512;       // a workgroup takes several column groups only while the launch keeps this many workgroups ("pairs_wgs")
