@@ -498,12 +498,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restri
         }
     }
     for (int e = threadIdx.x; e < c; e += 256) {
-        double v0 = 0.0, v1 = 0.0;
-        for (int k = 0; k < slots; ++k) { v0 += sums[(long)(2 * k) * c + e]; v1 += sums[(long)(2 * k + 1) * c + e]; }
+        const float is = invstd[e], mu = mean[e], ga = gamma[e];   // requested together with the slab rows
+        double v0, v1;
+        urn_slab_sum2(sums + e, c, slots, v0, v1);
         s_c0[e] = (float)(v0 * inv_n);
         s_c1[e] = (float)(v1 * inv_n);
-        const float is = invstd[e];
-        s_is[e] = is; s_mu[e] = mean[e]; s_a[e] = gamma[e] * is;
+        s_is[e] = is; s_mu[e] = mu; s_a[e] = ga * is;
         if (blockIdx.x == 0) { dbeta[e] += (float)v0; dgamma[e] += (float)v1; }
     }
     __syncthreads();

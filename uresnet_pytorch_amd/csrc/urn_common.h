@@ -45,3 +45,23 @@ __device__ __forceinline__ uint64_t urn_mix(uint64_t k)
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef __HIPCC__
+// v0 = sum_k p[(2k) * ld], v1 = sum_k p[(2k + 1) * ld] over the `slots` rows of an accumulated-statistics slab, added in slot
+// order (the result does not depend on how the loads are scheduled).  The loads of eight slots are issued together: a plain
+// loop waits for every pair of loads before it asks for the next (ISA: load, load, s_waitcnt vmcnt(1), add, vmcnt(0), add,
+// branch) -- eight dependent round trips, 4-5 us at the head of every kernel that derives a BatchNorm's coefficients.
+__device__ __forceinline__ void urn_slab_sum2(const double *p, long ld, int slots, double &v0, double &v1)
+{
+    v0 = 0.0; v1 = 0.0;
+    int k = 0;
+    for (; k + 8 <= slots; k += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = p[(long)(2 * (k + j)) * ld]; b[j] = p[(long)(2 * (k + j) + 1) * ld]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v0 += a[j]; v1 += b[j]; }
+    }
+    for (; k < slots; ++k) { v0 += p[(long)(2 * k) * ld]; v1 += p[(long)(2 * k + 1) * ld]; }
+}
+#endif

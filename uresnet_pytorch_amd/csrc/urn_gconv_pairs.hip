@@ -149,14 +149,15 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
                 const int ch = sl ? e - g.xs_split : e;
                 const double *p = g.xs_sums[sl] + ch;
                 const int ld = g.xs_ld[sl];
-                double v0 = 0.0, v1 = 0.0;
-                for (int k = 0; k < g.xs_slots; ++k) { v0 += p[(long)(2 * k) * ld]; v1 += p[(long)(2 * k + 1) * ld]; }
+                const float gam = g.xs_gamma[e], bet = g.xs_beta[e];   // requested together with the slab rows
+                double v0, v1;
+                urn_slab_sum2(p, ld, g.xs_slots, v0, v1);
                 const double mu = v0 * inv_n;
                 double var = v1 * inv_n - mu * mu;
                 if (var < 0.0) var = 0.0;
                 const double is = rsqrt(var + g.fin_eps);
-                const float sc = g.xs_gamma[e] * (float)is;
-                const float sh = fmaf(-(float)mu, sc, g.xs_beta[e]);
+                const float sc = gam * (float)is;
+                const float sh = fmaf(-(float)mu, sc, bet);
                 s_xf[e] = sc; s_xf[cin + e] = sh;
                 if (keep) {
                     g.xs_mean[e] = (float)mu; g.xs_invstd[e] = (float)is; g.xs_scale[e] = sc; g.xs_shift[e] = sh;
