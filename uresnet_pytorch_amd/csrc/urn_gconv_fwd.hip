@@ -248,6 +248,61 @@ __global__ void k_gconv_small(const float *__restrict__ x, const float *__restri
     y[t] = acc;
 }
 
+
+// The 1-channel stem (reference uresnet_sparse.py:21: SubmanifoldConvolution(d, 1, m, 3)): y[j][:] = sum_o x[tbl[o][j]] * w[o][:].
+// Thread = (row, 4 output columns); the 27 table words of the row are requested together, then the 27 input values, then
+// 27 x 4 FMAs -- two round trips per row where the generic fallback (one thread per output element, table word -> value ->
+// next offset) makes 54 dependent ones (25.6 us at 50k rows, plus two more launches for the BatchNorm statistics).  With
+// part_slots > 0 the column sums / sums of squares of y are ADDED into row (workgroup % part_slots) of `part`
+// ([slots][2][cout] fp64, the layout the consuming convolution reads: urn_gconv_args.xs_sums).
+template <int CG>   // cout / 4
+__global__ __launch_bounds__(256) void k_gconv_stem(const float *__restrict__ x, const float *__restrict__ wt, const int *__restrict__ tbl,
+                                                    long ld, int K, long n_out, float *__restrict__ y, double *part, int part_slots)
+{
+    constexpr int COUT = 4 * CG, RPB = 256 / CG;           // rows per workgroup
+    __shared__ float s_w[27 * COUT];
+    __shared__ double s_red[4][2][COUT];
+    const int tid = threadIdx.x, cg = tid % CG, rl = tid / CG;
+    for (int e = tid; e < K * COUT; e += 256) s_w[e] = wt[e];     // wt[o][c] (cin == 1)
+    const long row = (long)blockIdx.x * RPB + rl;
+    const bool ok = row < n_out;
+    int idx[27];
+#pragma unroll
+    for (int o = 0; o < 27; ++o) idx[o] = (ok && o < K) ? tbl[(long)o * ld + row] : -1;
+    float xv[27];
+#pragma unroll
+    for (int o = 0; o < 27; ++o) xv[o] = x[idx[o] >= 0 ? idx[o] : 0];
+    __syncthreads();
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 27; ++o) {
+        const float v = idx[o] >= 0 ? xv[o] : 0.f;
+        const f32x4 w = *(const f32x4 *)(s_w + o * COUT + 4 * cg);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fmaf(v, w[k], acc[k]);
+    }
+    if (ok) *(f32x4 *)(y + row * COUT + 4 * cg) = acc;
+    if (part_slots <= 0) return;
+    double s0[4], s1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s0[k] = ok ? (double)acc[k] : 0.0; s1[k] = ok ? (double)acc[k] * (double)acc[k] : 0.0; }
+    // lanes with the same column group are CG apart: butterfly over the row bits of the lane index
+#pragma unroll
+    for (int m = CG; m < 64; m <<= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += __shfl_xor(s0[k], m); s1[k] += __shfl_xor(s1[k], m); }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < CG)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_red[wave][0][4 * lane + k] = s0[k]; s_red[wave][1][4 * lane + k] = s1[k]; }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+        const int which = tid / COUT, col = tid - which * COUT;
+        const double v = s_red[0][which][col] + s_red[1][which][col] + s_red[2][which][col] + s_red[3][which][col];
+        unsafeAtomicAdd(&part[((long)(blockIdx.x % (unsigned)part_slots) * 2 + which) * COUT + col], v);
+    }
+}
+
 struct Pick { int mb, nb; };
 
 // tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
@@ -379,6 +434,20 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     hipStream_t st = (hipStream_t)stream;
     const int ks = u->cin / 16;
     const bool mfma_ok = (u->cin % 16 == 0) && (u->cout % 16 == 0) && u->K <= 28;
+    if (!mfma_ok && u->cin == 1 && (u->cout == 16 || u->cout == 32 || u->cout == 64) && u->K <= 27 && !u->flip && !u->res && !u->xf_scale &&
+        !u->xs_sums[0] && (u->epilogue == 0 || (u->epilogue == 1 && u->part_slots > 0 && u->part)) && (u->ldx == 0 || u->ldx == 1) &&
+        (u->ldy == 0 || u->ldy == u->cout)) {
+        // the 1-channel stem, with the statistics of its output accumulated for the consuming BatchNorm
+        const int slots = u->epilogue == 1 ? u->part_slots : 0;
+        const int cg = u->cout / 4, rpb = 256 / cg;
+        const dim3 grid((unsigned)urn_cdiv(u->n_out, rpb));
+        if (cg == 4) hipLaunchKernelGGL(k_gconv_stem<4>, grid, dim3(256), 0, st, u->x, u->wt, u->tbl, (long)u->ld, u->K, (long)u->n_out, u->y, u->part, slots);
+        else if (cg == 8) hipLaunchKernelGGL(k_gconv_stem<8>, grid, dim3(256), 0, st, u->x, u->wt, u->tbl, (long)u->ld, u->K, (long)u->n_out, u->y, u->part, slots);
+        else hipLaunchKernelGGL(k_gconv_stem<16>, grid, dim3(256), 0, st, u->x, u->wt, u->tbl, (long)u->ld, u->K, (long)u->n_out, u->y, u->part, slots);
+        if (n_tiles) *n_tiles = slots;
+        URN_LAUNCH_CHECK();
+        return URN_OK;
+    }
     if (!mfma_ok) {
         if (u->xf_scale || u->epilogue) { urn_set_error("urn_gconv_fwd_ex: fusions need channel counts that are multiples of 16"); return URN_EUNSUPPORTED; }
         hipLaunchKernelGGL(k_gconv_small, dim3(urn_cdiv(u->n_out * u->cout, 256)), dim3(256), 0, st, u->x, u->wt, u->tbl,

@@ -343,25 +343,44 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             esc[c] = g.e_scale[col]; esh[c] = g.e_shift[col]; emu[c] = g.e_mean[col]; eis[c] = g.e_invstd[col];
         }
     }
-    for (int lr = 4 * gi + q; lr < rows_here; lr += 4 * G) {
-        const long row = row0 + lr;
+    // four row groups per pass: their residual / BatchNorm-input elements are requested together before the first is used
+    // (one request per loop iteration made every iteration a round trip: 4 at T = 64, G = 4)
+    for (int lr0 = 4 * gi + q; lr0 < rows_here; lr0 += 16 * G) {
+        float rv[4][NC], xg[4][NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int col = col0 + 16 * c + r;
-            float v = 0.f;
-            for (int k = 0; k < G; ++k) v += s_slab[(long)k * slab_words + (long)lr * LDW + (col - colw)];
-            if (g.res) v += g.res[row * cout + col];
-            if (g.epi == 1) {
-                s0[c] += (double)v;
-                s1[c] += (double)v * (double)v;
-            } else if (g.epi == 2) {
-                const float xv = g.e_x[row * cout + col];
-                if (!(fmaf(xv, esc[c], esh[c]) > 0.f)) v = 0.f;
-                const double xh = ((double)xv - (double)emu[c]) * (double)eis[c];
-                s0[c] += (double)v;
-                s1[c] += (double)v * xh;
+        for (int u = 0; u < 4; ++u) {
+            const int lr = lr0 + 4 * G * u;
+            const long row = row0 + lr;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = col0 + 16 * c + r;
+                rv[u][c] = (g.res && lr < rows_here) ? g.res[row * cout + col] : 0.f;
+                xg[u][c] = (g.epi == 2 && lr < rows_here) ? g.e_x[row * cout + col] : 0.f;
             }
-            g.y[row * g.ldy + col] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int lr = lr0 + 4 * G * u;
+            if (lr >= rows_here) break;
+            const long row = row0 + lr;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = col0 + 16 * c + r;
+                float v = 0.f;
+                for (int k = 0; k < G; ++k) v += s_slab[(long)k * slab_words + (long)lr * LDW + (col - colw)];
+                v += rv[u][c];
+                if (g.epi == 1) {
+                    s0[c] += (double)v;
+                    s1[c] += (double)v * (double)v;
+                } else if (g.epi == 2) {
+                    const float xv = xg[u][c];
+                    if (!(fmaf(xv, esc[c], esh[c]) > 0.f)) v = 0.f;
+                    const double xh = ((double)xv - (double)emu[c]) * (double)eis[c];
+                    s0[c] += (double)v;
+                    s1[c] += (double)v * xh;
+                }
+                g.y[row * g.ldy + col] = v;
+            }
         }
     }
     if (g.epi == 0) return;

@@ -453,7 +453,8 @@ struct urn_net {
         y.x = dst ? dst : arena.f32(n_out * c.cout);
         const bool mfma = (c.cin % 16 == 0) && (c.cout % 16 == 0);
         const bool stats = c0.bn != nullptr && training;   // eval: running statistics, nothing to collect
-        const bool acc = sums_mode() && mfma;         // accumulated statistics on the producing side
+        const bool stem16 = c.cin == 1 && (c.cout == 16 || c.cout == 32 || c.cout == 64) && c.K == 27 && !res && !xf && !dst;   // k_gconv_stem
+        const bool acc = sums_mode() && (mfma || stem16);   // accumulated statistics on the producing side
         const bool xs = xf && in.st.part != nullptr;  // ... and on the consuming side (the input carries its sums)
         double *part = nullptr;
         if (stats) {
@@ -507,7 +508,7 @@ struct urn_net {
         }
         int n_part = 0;
         check(urn_gconv_fwd_ex(&a, &n_part, st));
-        if (stats && !mfma) {   // the VALU fallback (1-channel stem) has no epilogue: separate passes
+        if (stats && !mfma && !acc) {   // the VALU fallback has no epilogue: separate passes
             check(urn_bn_stats_partial(y.x, n_out, c.cout, part, &n_part, st));
             for (int i = 0; i < 2; ++i) {
                 if (!cons[i].bn) continue;
