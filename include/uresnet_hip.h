@@ -236,7 +236,15 @@ typedef struct {
      * scn.NetworkInNetwork).  pairs_tile == 0: the dense-table kernels.  fp32 operands only. */
     const int32_t *pairs;
     int pairs_tile;
+    /* Optional, pair-list kernel only: the weights of `wt` once more in MFMA-fragment order,
+     *   wt_frag[((o * (cout / 16) + cb) * (cin / 16) + kb) * 256 + (q * 16 + r) * 4 + i] = wt[o][16 cb + r][16 kb + 4 q + i]
+     * (urn_weight_fragments).  A wave then reads the 16 x 16 block of an offset as ONE contiguous kilobyte (8 cache lines)
+     * instead of 16 rows of 64 bytes (16 half-used lines): the kernel is bound by the cache lines a CU can address per
+     * cycle, and the weight block is fetched again for nearly every block of 16 rules.  NULL: rows of wt. */
+    const float *wt_frag;
 } urn_gconv_args;
+/* wt (K, cout, cin) -> fragment order (see urn_gconv_args.wt_frag); cin, cout multiples of 16 */
+int urn_weight_fragments(const float *wt, int K, int cout, int cin, float *wt_frag, void *stream);
 int64_t urn_gconv_part_bytes(int64_t n_out, int cout);
 int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);
 /* weight gradient with the same input transform: x rows are used as relu(x*scale+shift) */

@@ -244,3 +244,33 @@ def test_pairs_fused_epilogues_match_tile_kernel(dev):
         assert rel(outs[1][0], outs[0][0]) < 1e-6, (cin, cout, epi)
         assert np.array_equal(outs[1][0][:, cout:], np.zeros((n, 16), np.float32)), 'wrote outside its column block'
         assert rel(outs[1][1], outs[0][1]) < 1e-6, (cin, cout, epi, outs[1][1][:, :4], outs[0][1][:, :4])
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 16), (32, 48), (64, 32), (80, 80), (160, 80)])
+def test_pairs_fragment_ordered_weights_give_the_same_bits(dev, cin, cout):
+    """urn_weight_fragments + urn_gconv_args.wt_frag: the same operands in another memory order -- identical results"""
+    from uresnet_pytorch_amd import lib as _l, sparse_ops as so
+    L = _l.load()
+    S = 32
+    c, f = cloud(11, S, 2500, 2)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
+    n = geo.n[0]
+    g = torch.Generator(device='cpu').manual_seed(cin + cout)
+    x = torch.randn(n, cin, generator=g).to(dev)
+    wt = (torch.randn(27, cout, cin, generator=g) * 0.1).to(dev)
+    wf = torch.empty_like(wt)
+    _l.check(L.urn_weight_fragments(wt.data_ptr(), 27, cout, cin, wf.data_ptr(), _l.stream()), 'weight_fragments')
+    # the layout the header states
+    o, cb, kb, q, r, i = 5, cout // 16 - 1, cin // 16 - 1, 2, 7, 3
+    assert float(wf.reshape(-1)[((o * (cout // 16) + cb) * (cin // 16) + kb) * 256 + (q * 16 + r) * 4 + i]) == float(wt[o, 16 * cb + r, 16 * kb + 4 * q + i])
+    pl = geo.pairs['nbr'][0]
+    outs = []
+    for frag in (None, wf):
+        y = torch.empty(n, cout, device=dev)
+        a = _l.GConvArgs()
+        a.x = x.data_ptr(); a.wt = wt.data_ptr(); a.tbl = geo.nbr[0].data_ptr(); a.ld = geo.ld; a.K = 27; a.flip = 0; a.n_out = n
+        a.cin = cin; a.cout = cout; a.y = y.data_ptr(); a.pairs = pl[0].data_ptr(); a.pairs_tile = pl[1]
+        a.wt_frag = None if frag is None else frag.data_ptr()
+        _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])

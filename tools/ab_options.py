@@ -10,7 +10,7 @@ from uresnet_pytorch_amd import lib as L_, parallel
 from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
 from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
 L = L_.load(); dev = torch.device('cuda:0')
-DEFAULTS = {'pairs_waves': 2560, 'pairs_wgs': 512, 'dw_blocks': 768, 'pairs_deep': 1, 'pairs_max_cin': 80, 'pairs_max_cout': 999,
+DEFAULTS = {'pairs_waves': 2560, 'pairs_wgs': 512, 'dw_blocks': 768, 'pairs_deep': 2, 'pairs_max_cin': 80, 'pairs_max_cout': 999,
             'pairs_nc': 0, 'pairs_split': 0, 'pairs_cbg': 0, 'dw_split': 2, 'dw_2stage': 0}
 flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=5, SPATIAL_SIZE=512, NUM_CLASS=5)
 torch.manual_seed(0)

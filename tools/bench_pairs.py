@@ -11,7 +11,7 @@ geo = so.SparseGeometry(torch.from_numpy(blob['data'][:, :4].astype(np.int32)).t
 print('n', geo.n, 'rules', geo.rules)
 
 
-def run(kind, level, cin, cout, pairs, reps=30, xf=False):
+def run(kind, level, cin, cout, pairs, reps=30, xf=False, frag=False):
     if kind == 'nbr':
         tbl, K, n_out, n_in, pl = geo.nbr[level], 27, geo.n[level], geo.n[level], geo.pairs['nbr'][level]
     elif kind == 'chd':
@@ -29,6 +29,10 @@ def run(kind, level, cin, cout, pairs, reps=30, xf=False):
         a.xf_scale = sc.data_ptr(); a.xf_shift = sh.data_ptr()
     if pairs:
         a.pairs = None if pl[0] is None else pl[0].data_ptr(); a.pairs_tile = pl[1]
+    if frag:
+        wf = torch.empty_like(wt)
+        L_.check(L.urn_weight_fragments(wt.data_ptr(), K, cout, cin, wf.data_ptr(), L_.stream()))
+        a.wt_frag = wf.data_ptr()
     st = L_.stream()
 
     def call():
@@ -53,11 +57,11 @@ for kind, lv, ci, co in shapes:
     out.append('tile %.0f' % t_tile)
     variants = [('auto', 0, 0)]
     if mode == 'abl':
-        variants = [('dbg%d' % d, -d, 0) for d in (0, 1, 2, 4, 8, 16, 32, 1 | 2 | 4 | 8)]
+        variants = [('dbg%d' % d, -d, 0) for d in (0, 32, 64, 96, 128)]
     if mode == 'cbg':
         variants = [('cbg%d/nc%d/G%d' % (cb, nc, G), nc, G, cb) for cb in (0, 1, 2) for nc in (1, 2) for G in (2, 8)]
     if mode == 'deep':
-        variants = [('one set', 0, 0, 0, 0), ('three sets', 0, 0, 0, 1)]
+        variants = [('one set', 0, 0, 0, 0), ('three sets', 0, 0, 0, 14)]
     if mode == 'sweep':
         variants += [('nc%d/G%d' % (nc, G), nc, G) for nc in (1, 2) for G in (1, 2, 4)]
     for name, nc, G, *rest in variants:
@@ -67,6 +71,7 @@ for kind, lv, ci, co in shapes:
         L.urn_set_option(b'pairs_nc', max(nc, 0)); L.urn_set_option(b'pairs_split', G)
         out.append('%s %.0f' % (name, min(run(kind, lv, ci, co, True) for _ in range(3))))
     L.urn_set_option(b'pairs_nc', 0); L.urn_set_option(b'pairs_split', 0); L.urn_set_option(b'gconv_dbg', 0); L.urn_set_option(b'pairs_cbg', 0)
+    out.append('frag %.0f' % min(run(kind, lv, ci, co, True, frag=True) for _ in range(3)))
     out.append('xf: tile %.0f pairs %.0f' % (min(run(kind, lv, ci, co, False, xf=True) for _ in range(2)),
                                              min(run(kind, lv, ci, co, True, xf=True) for _ in range(2))))
     print('%s L%d %3d->%3d  %s' % (kind, lv, ci, co, ' | '.join(out)), flush=True)

@@ -650,6 +650,29 @@ __global__ void k_transpose_w(const float *__restrict__ w, int a, int b, float *
     }
 }
 
+// wt (K, cout, cin) -> fragment order (urn_gconv_args.wt_frag): thread = one 16-byte piece of the destination (coalesced
+// writes; the source rows are L2-resident weights)
+__global__ void k_weight_fragments(const float *__restrict__ wt, long total4, int cout, int cin, float *__restrict__ wf)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    const int lane = (int)(e & 63), r = lane & 15, q = lane >> 4;
+    long f = e >> 6;                         // fragment index = (o * (cout / 16) + cb) * (cin / 16) + kb
+    const int kbn = cin / 16, cbn = cout / 16;
+    const int kb = (int)(f % kbn); f /= kbn;
+    const int cb = (int)(f % cbn); const long o = f / cbn;
+    *(f32x4 *)(wf + e * 4) = *(const f32x4 *)(wt + ((long)o * cout + 16 * cb + r) * cin + 16 * kb + 4 * q);
+}
+
+extern "C" int urn_weight_fragments(const float *wt, int K, int cout, int cin, float *wt_frag, void *stream)
+{
+    URN_CHECK_ARG(wt && wt_frag && K > 0 && cout > 0 && cin > 0 && cout % 16 == 0 && cin % 16 == 0, "channel counts must be multiples of 16");
+    const long total4 = (long)K * cout * cin / 4;
+    hipLaunchKernelGGL(k_weight_fragments, dim3(urn_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, wt, total4, cout, cin, wt_frag);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
 extern "C" int urn_transpose_w(const float *w, int K, int a, int b, float *wt, void *stream)
 {
     URN_CHECK_ARG(w && wt && K > 0 && a > 0 && b > 0, "bad argument");

@@ -311,6 +311,7 @@ int g_opt_precision = 0;   // default MFMA operand precision of the gather convo
 extern int g_dw_pairs;
 extern int g_pairs_deep;
 extern int g_dw_2stage;
+extern int g_net_wfrag;
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
 static const int g_opt_fin_in_kernel = 0;   // (the in-kernel finalize lived in the removed 64x16 LDS kernel)
@@ -336,8 +337,9 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "pairs_nc")) { g_pairs_nc = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_cbg")) { g_pairs_cbg = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_wgs")) { g_pairs_wgs = (int)value; return URN_OK; }
-    if (!strcmp(key, "pairs_deep")) { g_pairs_deep = value != 0; return URN_OK; }
+    if (!strcmp(key, "pairs_deep")) { g_pairs_deep = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_pairs")) { g_dw_pairs = value != 0; return URN_OK; }
+    if (!strcmp(key, "net_wfrag")) { g_net_wfrag = value != 0; return URN_OK; }
     if (!strcmp(key, "dw_2stage")) { g_dw_2stage = value != 0; return URN_OK; }
     if (!strcmp(key, "dwp_cap")) { g_dwp_cap = value >= 1 && value <= 5 ? (int)value : 2; return URN_OK; }
     if (!strcmp(key, "dwp_dbg")) { g_dwp_dbg = (int)value; return URN_OK; }
@@ -464,7 +466,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     const Pick p = pick_tile(ks, u->cout / 16, u->n_out, split);
     GArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = u->x; a.wt = u->wt; a.tbl = u->tbl; a.ld = (long)u->ld; a.K = u->K; a.flip = u->flip; a.n_cap = (long)u->n_out;
+    a.x = u->x; a.wt = u->wt; a.wfrag = u->wt_frag; a.tbl = u->tbl; a.ld = (long)u->ld; a.K = u->K; a.flip = u->flip; a.n_cap = (long)u->n_out;
     a.cout = u->cout; a.cin = u->cin; a.res = u->res; a.y = u->y; a.xf_scale = u->xf_scale; a.xf_shift = u->xf_shift; a.epi = u->epilogue;
     a.part = u->part; a.e_x = u->e_x; a.e_scale = u->e_scale; a.e_shift = u->e_shift; a.e_mean = u->e_mean;
     a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg;

@@ -4,6 +4,7 @@
 
 struct GArgs {
     const float *x, *wt;
+    const float *wfrag;   // optional (pair-list kernel): the same weights in MFMA-fragment order, see urn_gconv_args.wt_frag
     const int *tbl;
     long ld;
     int K, flip;

@@ -99,7 +99,7 @@ extern "C" int urn_pairs_build(int n_tables, const int32_t *const *tbl, const in
 // ------------------------------------------------------------------------------------------------ convolution
 // KC: 16-channel groups per contraction chunk (cin = 16 * KC * nch); NC: 16-column blocks per wave; XF: rows are used as
 // relu(x * scale + shift) (folded BatchNorm+ReLU of the input)
-template <int KC, int NC, int XF>
+template <int KC, int NC, int XF, int DEEP>
 __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_pairs(GArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -137,7 +137,10 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
     const int *blk_t = hdr + URN_PAIRS_HDR;
     const int *blk_p = blk_t + urn_pairs_tpad(K, T);
     const int nblk = ident ? (rows_here + 15) >> 4 : hdr[0];
-    const int b0 = nblk * gi / G, b1 = nblk * (gi + 1) / G;   // nblk <= 27 * 8, G <= 16
+    const int b0 = nblk * gi / G;
+    // (g.dbg: timing-only ablations of whole phases, tools/bench_pairs.py abl: 32 = no block loop, 64 = return before the epilogue,
+    //  128 = one block per wave)
+    const int b1 = (g.dbg & 32) ? b0 : ((g.dbg & 128) ? min(b0 + 1, nblk * (gi + 1) / G) : nblk * (gi + 1) / G);   // nblk <= 27 * 8, G <= 16
 
     if constexpr (XF != 0) {
         if (g.xs_sums[0] != nullptr) {
@@ -196,8 +199,20 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
 #pragma unroll
         for (int j = 0; j < KC; ++j) a[j] = *(const f32x4 *)(src + 16 * j);
     };
+    // weight block of offset t, columns of this wave, channel chunk ch: from the fragment-ordered copy when the call has one
+    // (one contiguous kilobyte per 16 x 16 block: 8 cache lines; the rows of wt are 16 half-used lines per block, and the
+    // kernel is bound by the lines a CU can address per cycle)
+    const int kbn = cin / 16;
     auto load_w = [&](f32x4 (&w)[KC][NC], int t, int ch) {
         const int o = g.flip ? (K - 1 - t) : t;
+        if (g.wfrag) {
+            const float *src = g.wfrag + (((long)o * (cout / 16) + col0 / 16) * kbn + ch * KC) * 256 + lane * 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + ((long)c * kbn + j) * 256);
+            return;
+        }
         const float *src = g.wt + ((long)o * cout + col0 + r) * cin + ch * (16 * KC) + 4 * q;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
@@ -205,9 +220,8 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + (long)(16 * c) * cin + 16 * j);
     };
 
-    bool deep_path = false;
-    if constexpr (KC == 1) deep_path = nch == 1 && g.p_deep;   // compiled for 16-channel inputs only: the other shapes keep their registers
-    if constexpr (KC == 1) if (deep_path) {
+    // (DEEP is a template parameter: the rotating sets cost registers in every instantiation that contains them)
+    if constexpr (DEEP != 0) {
         // One channel chunk (cin = 16 KC; enabled by the launcher for KC == 1): THREE row-register sets rotate, so
         // that the rows of blocks b + 1 and b + 2 are in flight while block b is multiplied (one set in flight left a wave
         // at the unpipelined gather rate: 3 wave-loads/us against 20 with four in flight, tools/ubench/gather_rate.hip).
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             }
         }
     }
-    if (!deep_path)
+    if constexpr (DEEP == 0)
     // Steps s = (block, channel chunk).  The gathered rows of step s + 1 are requested before the MFMAs of step s and the
     // pair words three blocks ahead.  The weight fragments stay in registers while the offset (and chunk) does not
     // change; when it does they are requested BEFORE the next step's rows, so that waiting for them (s_waitcnt vmcnt(N)
@@ -329,6 +343,7 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             t_c = t_n; tv_n = tv_nn; tv_nn = tv_n3;
         }
     }
+    if (g.dbg & 64) return;
     __syncthreads();
 
     // epilogue: wave (cg, gi) finishes columns [col0, col0 + 16 NC) of the rows gi, gi + G, ... in groups of 4 (q)
@@ -413,15 +428,23 @@ int g_pairs_waves = 2560;    // a launch is split G ways until it has about this
 int g_pairs_nc = 0;          // force the column blocks per wave (urn_set_option "pairs_nc"), 0 = automatic
 int g_pairs_split = 0;
 int g_pairs_wgs = 512;       // a workgroup takes several column groups only while the launch keeps this many workgroups ("pairs_wgs")
-int g_pairs_deep = 1;        // three rotating row-register sets for 16-channel inputs (urn_set_option "pairs_deep")
+int g_pairs_deep = 2;        // bit KC set: three rotating row-register sets for inputs of 16 KC channels (KC <= 3; urn_set_option "pairs_deep")
 int g_pairs_cbg = 0;          // most column groups per workgroup (urn_set_option "pairs_cbg"), 0 = as many as fit       // force G (urn_set_option "pairs_split"), 0 = automatic
 
 template <int KC, int NC>
 static void launch_pairs2(const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
 {
     const bool xf = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
-    if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0>), grid, block, lds, st, a);
+    // DEEP variants exist for one-chunk inputs of up to 48 channels and one column block per wave
+    if constexpr (KC <= 3 && NC == 1) {
+        if (a.p_deep) {
+            if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 1>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 1>), grid, block, lds, st, a);
+            return;
+        }
+    }
+    if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 0>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 0>), grid, block, lds, st, a);
 }
 
 // returns the number of partial rows (tiles), 0 when the shape has no instantiation
@@ -458,7 +481,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < g_pairs_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= 65536) ++G;
     if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= 65536) G = g_pairs_split;
     if (lds_bytes(G) > 65536) return 0;
-    a.p_split = G; a.p_cw = cw; a.p_deep = g_pairs_deep && kc == 1;   // measured: 16 -> 16 12 -> 11 us; wider rows 5-15 % slower (registers)
+    a.p_split = G; a.p_cw = cw; a.p_deep = ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1;   // bit KC of the option
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
     const size_t lds = lds_bytes(G);
 #define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs2<KCv, NCv>(a, grid, block, lds, st); return (int)ntiles; }

@@ -18,6 +18,7 @@
 
 int g_dw_group = 1;   // weight gradients per fork to the side stream (urn_set_option "dw_group"); measured: 1: 3.61 ms, 2: 3.66, 4: 3.64, 8: 3.74, 16: 3.85
 
+int g_net_wfrag = 1;       // fragment-ordered weight copies for the pair-list kernel (urn_set_option "net_wfrag")
 int g_dw_2stage = 0;       // weight gradients of the table kernel as per-chunk partial slabs + a fixed-order reduce instead of fp32 atomics (urn_set_option "dw_2stage")
 int g_dw_pairs = 0;        // weight gradients on the two-stage pair-list kernel (bitwise reproducible) instead of the atomics kernel (urn_set_option "dw_pairs")
 int g_net_side_probe = 4;   // candidate side streams tried by an executor's first backward (urn_set_option "net_side_probe"; 0/1 = keep the first)
@@ -178,6 +179,7 @@ struct urn_net {
         side = cand[best];
     }
     float *wt_all = nullptr;             // transposed copy of every conv weight, same offsets as params
+    float *wf_fwd = nullptr, *wf_bwd = nullptr;   // wt_all / params once more in MFMA-fragment order (urn_gconv_args.wt_frag)
     std::vector<ConvP *> convs;          // every conv, for the batched transpose
     int rc = URN_OK;
     float *trunk_out = nullptr;   // (n0, m) features after the last BNReLU
@@ -224,12 +226,20 @@ struct urn_net {
     bool live() const { return !arena.dry && rc == URN_OK && !arena.overflow; }
 
     // a gather convolution without fusions, on the compacted rule list of its table when the geometry carries one
+    // the fragment-ordered copy of a weight operand (wt_all + off -> wf_fwd + off, params + off -> wf_bwd + off)
+    const float *frag_of(const float *wt, int cin, int cout) const
+    {
+        if (!g_net_wfrag || !wf_fwd || cin % 16 || cout % 16) return nullptr;
+        if (wt >= wt_all && wt < wt_all + n_params) return wf_fwd + (wt - wt_all);
+        if (wt >= params && wt < params + n_params) return wf_bwd + (wt - params);
+        return nullptr;
+    }
     int gconv_plain(const float *x, const float *wt, const int32_t *tbl, int K, int flip, int64_t n_out, int cin, int cout,
                     const float *res, float *y)
     {
         urn_gconv_args a;
         memset(&a, 0, sizeof(a));
-        a.x = x; a.wt = wt; a.tbl = tbl; a.ld = geo.ld; a.K = K; a.flip = flip; a.n_out = n_out; a.cin = cin; a.cout = cout;
+        a.x = x; a.wt = wt; a.wt_frag = frag_of(wt, cin, cout); a.tbl = tbl; a.ld = geo.ld; a.K = K; a.flip = flip; a.n_out = n_out; a.cin = cin; a.cout = cout;
         a.res = res; a.y = y;
         geo.pairs_of(tbl, a.pairs, a.pairs_tile);
         return urn_gconv_fwd_ex(&a, nullptr, st);
@@ -473,7 +483,7 @@ struct urn_net {
         if (!live()) return y;
         urn_gconv_args a;
         memset(&a, 0, sizeof(a));
-        a.x = in.x; a.wt = wt_all + c.w; a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
+        a.x = in.x; a.wt = wt_all + c.w; a.wt_frag = frag_of(a.wt, c.cin, c.cout); a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
         a.cin = c.cin; a.cout = c.cout; a.res = res; a.y = y.x;
         a.ldy = dst ? ld_dst : 0;
         geo.pairs_of(tbl, a.pairs, a.pairs_tile);
@@ -560,7 +570,7 @@ struct urn_net {
             dw_launch(c, &b, dy, tbl_f, n_out, ld_dy, scratch);
             urn_gconv_args a;
             memset(&a, 0, sizeof(a));
-            a.x = dy; a.wt = params + c.w; a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
+            a.x = dy; a.wt = params + c.w; a.wt_frag = frag_of(a.wt, c.cout, c.cin); a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
             a.cin = c.cout; a.cout = c.cin; a.y = g; a.ldx = ld_dy;
             geo.pairs_of(tbl_b, a.pairs, a.pairs_tile);
             a.epilogue = 2; a.part = part;
@@ -794,6 +804,29 @@ extern "C" void urn_net_destroy(urn_net *n)
 struct TDesc { int K, a, b; long off; };
 struct TDescs { int n; TDesc d[URN_MAX_CONVS]; };
 
+// fragment-ordered copies (urn_gconv_args.wt_frag) of every conv weight with channel counts that are multiples of 16:
+// blockIdx.z = 0: of the transposed weights (forward operand), 1: of the parameters themselves (the input gradient's
+// operand: (K, cin, cout) read as (K, "cout" = cin, "cin" = cout)).  Thread = one 16-byte piece of the destination.
+__global__ void k_fragments_all(TDescs t, const float *__restrict__ wt_all, const float *__restrict__ params,
+                                float *__restrict__ wf_fwd, float *__restrict__ wf_bwd)
+{
+    const TDesc d = t.d[blockIdx.y];
+    if (d.a % 16 || d.b % 16) return;
+    const bool bwd = blockIdx.z != 0;
+    const float *src = (bwd ? params : wt_all) + d.off;
+    float *dst = (bwd ? wf_bwd : wf_fwd) + d.off;
+    const int cout = bwd ? d.a : d.b, cin = bwd ? d.b : d.a;
+    const int kbn = cin / 16, cbn = cout / 16;
+    const long total4 = (long)d.K * d.a * d.b / 4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63), r = lane & 15, q = lane >> 4;
+        long f = e >> 6;
+        const int kb = (int)(f % kbn); f /= kbn;
+        const int cb = (int)(f % cbn); const long o = f / cbn;
+        *(f32x4 *)(dst + e * 4) = *(const f32x4 *)(src + ((long)o * cout + 16 * cb + r) * cin + 16 * kb + 4 * q);
+    }
+}
+
 __global__ void k_transpose_all(TDescs t, const float *__restrict__ params, float *__restrict__ wt)
 {
     const TDesc d = t.d[blockIdx.y];
@@ -824,6 +857,8 @@ static void transpose_all(urn_net *net)
         for (const ConvP *c : net->convs) net->sum_channels += std::max(c->cin, c->cout);
     }
     net->wt_all = net->arena.f32(net->n_params);
+    net->wf_fwd = net->wf_bwd = nullptr;
+    if (g_net_wfrag) { net->wf_fwd = net->arena.f32(net->n_params); net->wf_bwd = net->arena.f32(net->n_params); }
     if (!net->live()) return;
     for (size_t base = 0; base < net->convs.size(); base += URN_MAX_CONVS) {
         TDescs t;
@@ -833,6 +868,9 @@ static void transpose_all(urn_net *net)
             t.d[i] = TDesc{c->K, c->cin, c->cout, (long)c->w};
         }
         hipLaunchKernelGGL(k_transpose_all, dim3(32, t.n), dim3(256), 0, net->st, t, net->params, net->wt_all);
+        if (net->wf_fwd)
+            hipLaunchKernelGGL(k_fragments_all, dim3(8, t.n, 2), dim3(256), 0, net->st, t, (const float *)net->wt_all, net->params,
+                               net->wf_fwd, net->wf_bwd);
     }
 }
 // ---- test hook: the folded BatchNorm+ReLU of the last training forward, per BatchNorm -------------------------------

@@ -35,7 +35,8 @@ class GConvArgs(ctypes.Structure):
                 ('xs_gamma', ctypes.c_void_p), ('xs_beta', ctypes.c_void_p), ('xs_mean', ctypes.c_void_p),
                 ('xs_invstd', ctypes.c_void_p), ('xs_scale', ctypes.c_void_p), ('xs_shift', ctypes.c_void_p),
                 ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p), ('precision', ctypes.c_int),
-                ('ldx', ctypes.c_int64), ('ldy', ctypes.c_int64), ('pairs', ctypes.c_void_p), ('pairs_tile', ctypes.c_int)]
+                ('ldx', ctypes.c_int64), ('ldy', ctypes.c_int64), ('pairs', ctypes.c_void_p), ('pairs_tile', ctypes.c_int),
+                ('wt_frag', ctypes.c_void_p)]
 
 
 class DenseGeom(ctypes.Structure):
@@ -79,6 +80,7 @@ SIGNATURES = {
     'urn_gconv_dw_pairs_scratch_bytes': (c_i64, [c_i64, c_int, c_int, c_int, c_int]),
     'urn_gconv_bwd_dw_pairs': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_i64,
                                        c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
+    'urn_weight_fragments': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'urn_transpose_w': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'urn_bn_scratch_bytes': (c_i64, [c_int]),
     'urn_bn_relu_fwd': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
