@@ -322,6 +322,9 @@ extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs, g
 // it wins for the strided pair and the narrow levels; the wide, small levels are faster on the LDS-staged 2-D tile kernel):
 // K == 8, or K == 27 with cin <= g_pairs_max_cin and cout <= g_pairs_max_cout; K == 1 only when g_pairs_nin is set
 static int g_pairs_max_cin = 80, g_pairs_max_cout = 999, g_pairs_nin = 0;
+// with fragment-ordered weights (urn_gconv_args.wt_frag) the wide inputs win on the pair lists too (96 -> 48: 33 us against 43 on
+// the tile kernel and 42 without fragments; 128 -> 64: 40 against 41 and 49)
+static int g_pairs_frag_wide = 1;
 static long g_opt_min_waves = 8192;
 
 extern "C" int urn_set_option(const char *key, int64_t value)
@@ -331,6 +334,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "gconv_min_waves")) { g_opt_min_waves = value; return URN_OK; }
     if (!strcmp(key, "gconv_kernel")) { g_opt_kernel = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_waves")) { g_pairs_waves = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_frag_wide")) { g_pairs_frag_wide = value != 0; return URN_OK; }
     if (!strcmp(key, "pairs_max_cin")) { g_pairs_max_cin = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_max_cout")) { g_pairs_max_cout = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_nin")) { g_pairs_nin = (int)value; return URN_OK; }
@@ -514,7 +518,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
         return URN_EUNSUPPORTED;
     }
     // compacted rule lists: the call carries the list of its table (or asks for the identity list of a 1x1 convolution)
-    const bool pairs_shape = u->K == 8 || (u->K == 1 && g_pairs_nin) || (u->K > 8 && u->cin <= g_pairs_max_cin && u->cout <= g_pairs_max_cout);
+    const bool pairs_shape = u->K == 8 || (u->K == 1 && g_pairs_nin) || (u->K > 8 && (u->cin <= g_pairs_max_cin || (u->wt_frag && g_pairs_frag_wide)) && u->cout <= g_pairs_max_cout);
     if (g_opt_kernel >= 7 && u->pairs_tile != 0 && a.prec == 0 && !in_kernel && pairs_shape && (u->pairs != nullptr || u->K == 1)) {
         a.pairs = u->pairs; a.p_tile = u->pairs_tile;
         const int npp = urn_gconv_pairs_launch(a, u->n_out, st);
