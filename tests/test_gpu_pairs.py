@@ -265,6 +265,7 @@ def test_pairs_fragment_ordered_weights_give_the_same_bits(dev, cin, cout):
     assert float(wf.reshape(-1)[((o * (cout // 16) + cb) * (cin // 16) + kb) * 256 + (q * 16 + r) * 4 + i]) == float(wt[o, 16 * cb + r, 16 * kb + 4 * q + i])
     pl = geo.pairs['nbr'][0]
     outs = []
+    L.urn_set_option(b'pairs_max_cin', 999)      # both calls on the pair-list kernel (without fragments cin > 80 takes the tile kernel)
     for frag in (None, wf):
         y = torch.empty(n, cout, device=dev)
         a = _l.GConvArgs()
@@ -273,4 +274,5 @@ def test_pairs_fragment_ordered_weights_give_the_same_bits(dev, cin, cout):
         a.wt_frag = None if frag is None else frag.data_ptr()
         _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
         outs.append(y)
+    L.urn_set_option(b'pairs_max_cin', 80)
     assert torch.equal(outs[0], outs[1])

@@ -493,7 +493,27 @@ __global__ __launch_bounds__(256) void k_dense_splitk_reduce(DenseArgs g, int Z)
         const int uy = (int)(v % g.Sub[1]); v /= g.Sub[1];
         const int uz = (int)(v % g.Sub[0]); const int b = (int)(v / g.Sub[0]);
         f32x4 s = g.bias ? *(const f32x4 *)(g.bias + 4 * k4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < Z; ++z) s += *(const f32x4 *)(g.slab + ((long)z * nsub + srow) * g.cout + 4 * k4);
+        {   // the slices are added in order, eight loads in flight (a plain loop waits for every load: Z round trips)
+            const float *p = g.slab + srow * g.cout + 4 * k4;
+            const long zs = nsub * g.cout;
+            int z = 0;
+            for (; z + 8 <= Z; z += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *(const f32x4 *)(p + (long)(z + k) * zs);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[k];
+            }
+            if (z + 4 <= Z) {
+                f32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = *(const f32x4 *)(p + (long)(z + k) * zs);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s += v[k];
+                z += 4;
+            }
+            for (; z < Z; ++z) s += *(const f32x4 *)(p + (long)z * zs);
+        }
         const long row = (long)b * g.Out[0] * g.Out[1] * g.Out[2] +
                          ((long)(g.p[0] + g.os[0] * uz) * g.Out[1] + (g.p[1] + g.os[1] * uy)) * g.Out[2] + (g.p[2] + g.os[2] * ux);
         float *dst = g.y + row * g.ldy + 4 * k4;

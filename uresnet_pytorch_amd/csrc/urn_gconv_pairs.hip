@@ -9,11 +9,12 @@
 //
 // One wave owns 16*NC output columns of a tile and a contiguous share [b0, b1) of the tile's block list (the list is
 // split G ways so that deep, small levels still fill the chip).  Per block it gathers the 16 input rows straight into
-// MFMA A fragments (global -> registers, 64 B per row and 16-channel group), keeps the weight fragments of the current
-// offset in registers (reloaded only when the offset changes), runs v_mfma_f32_16x16x4_f32 and adds the 16x16 result
-// into its PRIVATE fp32 slab in LDS with ds_add_f32 at the rows' positions in the tile.  A wave's adds execute in
-// program order and no two waves share a slab element, so the sum order is fixed by the list: results are bitwise
-// reproducible.  After one workgroup barrier the G partial slabs are summed in order g = 0..G-1 and the epilogue
+// MFMA fragments (global -> registers, 64 B per row and 16-channel group), keeps the weight fragments of the current
+// offset in registers (reloaded only when the offset changes), runs v_mfma_f32_16x16x4_f32 with the weights as the A
+// operand (lane (r, q) then holds 4 consecutive output columns of pair r) and adds the result into its PRIVATE fp32 slab
+// in LDS with one 16-byte read-modify-write per column block at the rows' positions in the tile (LDS float atomics were
+// 3-5x slower).  A wave's adds execute in program order and no two waves share a slab element, so the sum order is fixed
+// by the list: results are bitwise reproducible.  After one workgroup barrier the G partial slabs are summed in order g = 0..G-1 and the epilogue
 // (residual, BatchNorm statistics or BatchNorm-backward reduce, exactly as in the tile kernel) writes y.
 //
 // Padding pairs of a partly filled block gather row 0 and add into a trash row (index T) of the slab: no masks.
@@ -29,21 +30,30 @@
 struct PairsDesc { const int *tbl; long ld; int K; const int *n_dev; long n_cap; int T; int *out; int ntiles; };
 struct PairsDescs { int n; PairsDesc d[URN_PAIRS_MAX_TABLES]; };
 
-__global__ __launch_bounds__(128) void k_pairs_build(PairsDescs ds)
+// KK = compile-time table height (27 / 8; 0 = generic): with it the K table words of a row are requested together and the
+// loop over the table rows is straight-line code (a load inside a rolled loop is a round trip per table row)
+template <int KK>
+__device__ __forceinline__ void pairs_build_tile(const PairsDesc &d, int *s_cnt)
 {
-    const PairsDesc d = ds.d[blockIdx.y];
-    if ((int)blockIdx.x >= d.ntiles) return;
-    const int T = d.T, K = d.K;
+    const int T = d.T, K = KK ? KK : d.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (T <= 64 && wave) return;   // one wave per tile of 32 / 64 rows (no barrier is executed for them)
-    __shared__ int s_cnt[2];
     const long n_out = d.n_dev ? (long)*d.n_dev : d.n_cap;
     const long row = (long)blockIdx.x * T + tid;
     int *out = d.out + (long)blockIdx.x * urn_pairs_words(K, T);
     int *out_t = out + URN_PAIRS_HDR, *out_p = out_t + urn_pairs_tpad(K, T);
     int nb = 0;
-    for (int t = 0; t < K; ++t) {
-        const int v = (tid < T && row < n_out) ? d.tbl[(long)t * d.ld + row] : -1;
+    constexpr int NV = KK ? KK : 1;
+    int vals[NV];
+    if constexpr (KK != 0) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) vals[t] = (tid < T && row < n_out) ? d.tbl[(long)t * d.ld + row] : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < (KK ? KK : 27); ++t) {
+        if (KK == 0 && t >= K) break;
+        int v;
+        if constexpr (KK != 0) v = vals[t];
+        else v = (tid < T && row < n_out) ? d.tbl[(long)t * d.ld + row] : -1;
         const unsigned long long b = __ballot(v >= 0);
         const int my = __popcll(b & ((1ull << lane) - 1ull)), wcnt = __popcll(b);
         int base = 0, total = wcnt;
@@ -62,6 +72,17 @@ __global__ __launch_bounds__(128) void k_pairs_build(PairsDescs ds)
         nb += nblk_t;
     }
     if (tid == 0) out[0] = nb;
+}
+
+__global__ __launch_bounds__(128) void k_pairs_build(PairsDescs ds)
+{
+    const PairsDesc d = ds.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.ntiles) return;
+    if (d.T <= 64 && threadIdx.x >= 64) return;   // one wave per tile of 32 / 64 rows (no barrier is executed for them)
+    __shared__ int s_cnt[2];
+    if (d.K == 27) pairs_build_tile<27>(d, s_cnt);
+    else if (d.K == 8) pairs_build_tile<8>(d, s_cnt);
+    else pairs_build_tile<0>(d, s_cnt);
 }
 
 extern "C" int64_t urn_pairs_bytes(int64_t n_cap, int K, int tile)
