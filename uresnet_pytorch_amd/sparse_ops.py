@@ -233,6 +233,13 @@ def _gconv(x, wt, tbl, ld, K, flip, n_out, cin, cout, res=None, pairs=None):
     a.cin = cin; a.cout = cout; a.res = _l.ptr(res); a.y = y.data_ptr()
     a.pairs = None if pairs[0] is None else pairs[0].data_ptr()
     a.pairs_tile = pairs[1]
+    wf = None
+    if cin % 16 == 0 and cout % 16 == 0 and K > 1:
+        # the weights once more in MFMA-fragment order, as the executor hands them to the pair-list kernel (same kernel
+        # choice and the same bits on both routes)
+        wf = torch.empty_like(wt)
+        _l.check(L.urn_weight_fragments(_l.ptr(wt), K, cout, cin, wf.data_ptr(), _l.stream()), 'weight_fragments')
+        a.wt_frag = wf.data_ptr()
     _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
     return y
 
