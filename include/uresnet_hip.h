@@ -415,6 +415,11 @@ int64_t urn_net_workspace_bytes(urn_net *net, int num_levels, const int64_t *n, 
  * NEXT urn_net_forward (and its backward) only; without them the executor runs on the dense tables. */
 int urn_net_set_pairs(urn_net *net, int num_levels, const void *const *nbr_pairs, const void *const *chd_pairs,
                       const void *const *up_pairs, const int *tile_nbr, const int *tile_chd, const int *tile_up);
+/* Optional, before the integer phase of a step is enqueued: write the weight copies of the coming forward (transposed and
+ * both MFMA-fragment orders) into wbuf (3 * urn_net_param_count floats, owned by the caller, valid until that forward's
+ * backward has run), on the executor's side stream behind everything queued on `stream` so far -- beside the integer phase
+ * instead of in front of the first convolution.  urn_net_forward orders them in front of its launches. */
+int urn_net_prepare_weights(urn_net *net, const float *params, float *wbuf, int64_t wbuf_floats, void *stream);
 int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const int64_t *n, const void *const *nbr,
                     const void *const *chd, const void *const *up, const int32_t *row2site, int64_t n_rows,
                     const float *params, float *running, const float *site_feats, void *ws, int64_t ws_bytes,

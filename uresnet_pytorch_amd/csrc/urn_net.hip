@@ -180,6 +180,9 @@ struct urn_net {
     }
     float *wt_all = nullptr;             // transposed copy of every conv weight, same offsets as params
     float *wf_fwd = nullptr, *wf_bwd = nullptr;   // wt_all / params once more in MFMA-fragment order (urn_gconv_args.wt_frag)
+    float *ext_w = nullptr;              // urn_net_prepare_weights: the three copies live in the caller's buffer, already written
+    bool w_prepared = false;
+    hipEvent_t ev_w = nullptr;           // ... recorded behind them on the stream they were written on
     std::vector<ConvP *> convs;          // every conv, for the batched transpose
     int rc = URN_OK;
     float *trunk_out = nullptr;   // (n0, m) features after the last BNReLU
@@ -795,6 +798,7 @@ extern "C" void urn_net_destroy(urn_net *n)
 {
     if (!n) return;
     for (auto e : n->events) (void)hipEventDestroy(e);
+    if (n->ev_w) (void)hipEventDestroy(n->ev_w);
     if (n->side) (void)hipStreamDestroy(n->side);
     delete n;
 }
@@ -849,17 +853,18 @@ static void collect_convs(urn_net *net, ULevel &lv)
     for (auto &k : lv.post) { if (k.has_nin) net->convs.push_back(&k.nin); net->convs.push_back(&k.conv1); net->convs.push_back(&k.conv2); }
 }
 
-static void transpose_all(urn_net *net)
+static void collect_all_convs(urn_net *net)
 {
     if (net->convs.empty()) {
         net->convs.push_back(&net->stem); collect_convs(net, net->u);
         net->sum_channels = 0;
         for (const ConvP *c : net->convs) net->sum_channels += std::max(c->cin, c->cout);
     }
-    net->wt_all = net->arena.f32(net->n_params);
-    net->wf_fwd = net->wf_bwd = nullptr;
-    if (g_net_wfrag) { net->wf_fwd = net->arena.f32(net->n_params); net->wf_bwd = net->arena.f32(net->n_params); }
-    if (!net->live()) return;
+}
+
+// launches that write the transposed and the fragment-ordered copies of every conv weight
+static void launch_weight_copies(urn_net *net, const float *params, float *wt_all, float *wf_fwd, float *wf_bwd, hipStream_t st)
+{
     for (size_t base = 0; base < net->convs.size(); base += URN_MAX_CONVS) {
         TDescs t;
         t.n = (int)std::min((size_t)URN_MAX_CONVS, net->convs.size() - base);
@@ -867,11 +872,53 @@ static void transpose_all(urn_net *net)
             const ConvP *c = net->convs[base + i];
             t.d[i] = TDesc{c->K, c->cin, c->cout, (long)c->w};
         }
-        hipLaunchKernelGGL(k_transpose_all, dim3(32, t.n), dim3(256), 0, net->st, t, net->params, net->wt_all);
-        if (net->wf_fwd)
-            hipLaunchKernelGGL(k_fragments_all, dim3(8, t.n, 2), dim3(256), 0, net->st, t, (const float *)net->wt_all, net->params,
-                               net->wf_fwd, net->wf_bwd);
+        hipLaunchKernelGGL(k_transpose_all, dim3(32, t.n), dim3(256), 0, st, t, params, wt_all);
+        if (wf_fwd)
+            hipLaunchKernelGGL(k_fragments_all, dim3(8, t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
     }
+}
+
+static void transpose_all(urn_net *net)
+{
+    collect_all_convs(net);
+    // (the arena copies are always carved, so that the workspace model does not depend on urn_net_prepare_weights)
+    net->wt_all = net->arena.f32(net->n_params);
+    net->wf_fwd = net->wf_bwd = nullptr;
+    if (g_net_wfrag) { net->wf_fwd = net->arena.f32(net->n_params); net->wf_bwd = net->arena.f32(net->n_params); }
+    if (!net->live()) return;
+    if (net->w_prepared && net->ext_w) {
+        // written ahead of this call (urn_net_prepare_weights), possibly on the side stream: order them in front of the convs
+        net->w_prepared = false;
+        net->wt_all = net->ext_w;
+        net->wf_fwd = g_net_wfrag ? net->ext_w + net->n_params : nullptr;
+        net->wf_bwd = g_net_wfrag ? net->ext_w + 2 * net->n_params : nullptr;
+        if (net->ev_w) net->check(hipStreamWaitEvent(net->st, net->ev_w, 0) == hipSuccess ? URN_OK : URN_EHIP);
+        return;
+    }
+    launch_weight_copies(net, net->params, net->wt_all, net->wf_fwd, net->wf_bwd, net->st);
+}
+
+// The weight copies of the coming forward (transposed + both fragment orders; wbuf = 3 * urn_net_param_count floats owned by
+// the caller, valid until the backward of that forward has run), written NOW -- on the executor's side stream when it
+// has one, behind everything queued on `stream` so far (the optimizer step).  Called before the integer phase is enqueued,
+// the ~35 us of copy kernels run beside it instead of in front of the first convolution.  Optional: without it
+// urn_net_forward writes the copies itself.
+extern "C" int urn_net_prepare_weights(urn_net *net, const float *params, float *wbuf, int64_t wbuf_floats, void *stream)
+{
+    URN_CHECK_ARG(net && params && wbuf && wbuf_floats >= 3 * net->n_params, "null pointer or buffer smaller than 3 * urn_net_param_count floats");
+    collect_all_convs(net);
+    hipStream_t st = (hipStream_t)stream, ws = st;
+    if (!net->ev_w && hipEventCreateWithFlags(&net->ev_w, hipEventDisableTiming) != hipSuccess) { net->ev_w = nullptr; (void)hipGetLastError(); }
+    if (net->side && net->ev_w && !net->events.empty()) {
+        hipEvent_t e = net->events[net->ev_next++ % net->events.size()];
+        if (hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(net->side, e, 0) == hipSuccess) ws = net->side;
+    }
+    launch_weight_copies(net, params, wbuf, g_net_wfrag ? wbuf + net->n_params : nullptr, g_net_wfrag ? wbuf + 2 * net->n_params : nullptr, ws);
+    if (net->ev_w && hipEventRecord(net->ev_w, ws) != hipSuccess) return URN_EHIP;
+    if (!net->ev_w && ws != st) return URN_EHIP;
+    net->ext_w = wbuf; net->w_prepared = true;
+    URN_LAUNCH_CHECK();
+    return URN_OK;
 }
 // ---- test hook: the folded BatchNorm+ReLU of the last training forward, per BatchNorm -------------------------------
 // The fused path never writes a normalised tensor; what decides a ReLU mask is relu(x * scale + shift) with the scale /

@@ -137,6 +137,7 @@ SIGNATURES = {
     'urn_dense_bn_act_bwd_apply': (c_int, [c_void_p] * 16 + [c_i64, c_int, c_void_p]),
     'urn_net_create': (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, c_int, ctypes.POINTER(c_void_p)]),
     'urn_net_destroy': (None, [c_void_p]),
+    'urn_net_prepare_weights': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'urn_net_param_count': (c_i64, [c_void_p]),
     'urn_net_running_count': (c_i64, [c_void_p]),
     'urn_net_num_tensors': (c_int, [c_void_p]),

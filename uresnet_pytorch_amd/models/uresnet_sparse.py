@@ -49,6 +49,7 @@ class UResNet(torch.nn.Module):
         # everything that does not need the level counts goes BEFORE their read-back (geo.sync() inside forward):
         # host time after that synchronisation is exposed in the step, host time before it is not
         ex.flatten(c.device, tail=(self.linear.weight, self.linear.bias))
+        ex.prepare_weights()      # transposed / fragment-ordered weight copies on the side stream, beside the integer phase
         geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels, defer_sync=True)
         feats = so.input_features(geo, features)
         ex.prepare(geo, self.training)

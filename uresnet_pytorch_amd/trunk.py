@@ -34,6 +34,7 @@ class _Slot:
         self.token = None
         self.ws = None
         self.ws_bytes = 0
+        self.wbuf = None          # weight copies written ahead of the forward (prepare_weights)
 
     def busy(self):
         return self.token is not None and self.token() is not None
@@ -51,6 +52,7 @@ class TrunkExecutor:
         self.flat_grad = None
         self._ws_coef = {}
         self._prep = None
+        self._early_slot = None
         self._side_handles = 0
 
     # -- handle ------------------------------------------------------------------------
@@ -214,10 +216,21 @@ class TrunkExecutor:
             slot.ws = torch.empty(slot.ws_bytes, dtype=torch.uint8, device=geo.device)
         return slot.ws, slot.ws_bytes
 
+    def prepare_weights(self):
+        """The weight copies of the coming forward (transposed + fragment orders), enqueued NOW on the executor's side
+        stream: call it before the integer phase is enqueued, they then run beside it (urn_net_prepare_weights)."""
+        slot = self.acquire()
+        self._early_slot = slot
+        n3 = 3 * self.n_params
+        if slot.wbuf is None or slot.wbuf.numel() < n3 or slot.wbuf.device != self.flat.device:
+            slot.wbuf = torch.empty(n3, dtype=torch.float32, device=self.flat.device)
+        _l.check(_l.load().urn_net_prepare_weights(slot.handle, self.flat.data_ptr(), slot.wbuf.data_ptr(), n3, _l.stream()),
+                 'net_prepare_weights')
+
     def prepare(self, geo, training):
         """Host-side preparation of forward() that does not need the level counts; call it BEFORE geo.sync()."""
         Lv = geo.num_levels
-        slot = self.acquire()
+        slot, self._early_slot = (self._early_slot or self.acquire()), None
         need_bwd = bool(training and torch.is_grad_enabled())
         self._ws_model(slot, Lv, need_bwd)
         self._prep = dict(
