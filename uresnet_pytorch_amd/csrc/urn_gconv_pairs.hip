@@ -48,12 +48,7 @@ __device__ __forceinline__ void pairs_build_tile(const PairsDesc &d, int *s_cnt)
 #pragma unroll
         for (int t = 0; t < KK; ++t) vals[t] = (tid < T && row < n_out) ? d.tbl[(long)t * d.ld + row] : -1;
     }
-#pragma unroll
-    for (int t = 0; t < (KK ? KK : 27); ++t) {
-        if (KK == 0 && t >= K) break;
-        int v;
-        if constexpr (KK != 0) v = vals[t];
-        else v = (tid < T && row < n_out) ? d.tbl[(long)t * d.ld + row] : -1;
+    auto row_of_table = [&](int t, int v) {
         const unsigned long long b = __ballot(v >= 0);
         const int my = __popcll(b & ((1ull << lane) - 1ull)), wcnt = __popcll(b);
         int base = 0, total = wcnt;
@@ -70,6 +65,12 @@ __device__ __forceinline__ void pairs_build_tile(const PairsDesc &d, int *s_cnt)
         if (tid < nblk_t) out_t[nb + tid] = t;
         if (tid == 0) ((unsigned char *)(out + 1))[t] = (unsigned char)nb;   // first block of table row t (the weight gradient walks by t)
         nb += nblk_t;
+    };
+    if constexpr (KK != 0) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) row_of_table(t, vals[t]);
+    } else {
+        for (int t = 0; t < K; ++t) row_of_table(t, (tid < T && row < n_out) ? d.tbl[(long)t * d.ld + row] : -1);
     }
     if (tid == 0) out[0] = nb;
 }
@@ -212,11 +213,14 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             return;
         }
         pv = blk_p[(long)b * 16 + r];
-        tv = blk_t[b];   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
+        tv = (g.dbg & 512) ? 0 : blk_t[b];   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
     };
     f32x4 a_cur[KC], a_nxt[KC], w_cur[KC][NC];
+    // (g.dbg 256: every pair gathers row 0 -- the loads stay, their cache lines collapse to one; 512: the weight block of offset 0
+    //  for every block -- no reloads.  Timing only.)
+    const int row_mask = (g.dbg & 256) ? 0 : 0xFFFFFF;
     auto load_a = [&](f32x4 (&a)[KC], int pv, int ch) {
-        const float *src = g.x + (long)(pv & 0xFFFFFF) * g.ldx + ch * (16 * KC) + 4 * q;
+        const float *src = g.x + (long)(pv & row_mask) * g.ldx + ch * (16 * KC) + 4 * q;
 #pragma unroll
         for (int j = 0; j < KC; ++j) a[j] = *(const f32x4 *)(src + 16 * j);
     };
