@@ -314,6 +314,7 @@ extern int g_dw_2stage;
 extern int g_net_wfrag;
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
+static long long *g_opt_stamps = nullptr;
 static const int g_opt_fin_in_kernel = 0;   // (the in-kernel finalize lived in the removed 64x16 LDS kernel)
 static int g_opt_pipe = 0;
 static int g_opt_kernel = 7;   // 7 = compacted rule lists when the call carries them (urn_gconv_pairs.hip), else the 2-D tile; 6 = 2-D workgroup tile (urn_gconv_tile.hip); 3 = register gather (fallback for shapes without a tile instantiation)
@@ -350,6 +351,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "dwp_waves")) { g_dwp_waves = (int)value; return URN_OK; }
     if (!strcmp(key, "dwp_smax")) { g_dwp_smax = value > 0 && value <= 256 ? (int)value : 16; return URN_OK; }
     if (!strcmp(key, "pairs_split")) { g_pairs_split = (int)value; return URN_OK; }
+    if (!strcmp(key, "gconv_stamp_ptr")) { g_opt_stamps = (long long *)(uintptr_t)value; return URN_OK; }
     if (!strcmp(key, "gconv_dbg")) { g_opt_dbg = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_rb")) { g_tile_rb = (int)value; return URN_OK; }
     if (!strcmp(key, "tile_cb")) { g_tile_cb = (int)value; return URN_OK; }
@@ -473,7 +475,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     a.x = u->x; a.wt = u->wt; a.wfrag = u->wt_frag; a.tbl = u->tbl; a.ld = (long)u->ld; a.K = u->K; a.flip = u->flip; a.n_cap = (long)u->n_out;
     a.cout = u->cout; a.cin = u->cin; a.res = u->res; a.y = u->y; a.xf_scale = u->xf_scale; a.xf_shift = u->xf_shift; a.epi = u->epilogue;
     a.part = u->part; a.e_x = u->e_x; a.e_scale = u->e_scale; a.e_shift = u->e_shift; a.e_mean = u->e_mean;
-    a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg;
+    a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg; a.stamps = g_opt_stamps;
     a.prec = u->precision > 0 ? u->precision - 1 : g_opt_precision;   // 0 fp32, 1 bf16, 2 fp16
     a.ldx = u->ldx > 0 ? (long)u->ldx : (long)u->cin;
     a.ldy = u->ldy > 0 ? (long)u->ldy : (long)u->cout;

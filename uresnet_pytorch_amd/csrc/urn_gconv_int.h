@@ -40,6 +40,7 @@ struct GArgs {
     // rows per tile (64 / 128), split of a tile's block list over waves, columns per workgroup
     const int *pairs;
     int p_tile, p_split, p_cw, p_deep;
+    long long *stamps;   // diagnostics (urn_set_option "gconv_stamp_ptr"): 8 s_memtime values per wave of the pair-list kernel
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };
 

@@ -125,6 +125,15 @@ template <int KC, int NC, int XF, int DEEP>
 __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_pairs(GArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // diagnostics, compiled only with -DURN_PAIRS_STAMP (make CXXFLAGS+=...): s_memtime at the phase boundaries of every wave
+    // (urn_set_option "gconv_stamp_ptr"; tools/stamp_pairs.py)
+#ifdef URN_PAIRS_STAMP
+    long long *stamp = g.stamps ? g.stamps + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 : nullptr;
+#define URN_STAMP(i) do { if (stamp && (threadIdx.x & 63) == 0) stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define URN_STAMP(i) do { } while (0)
+#endif
+    URN_STAMP(0);
     const int T = g.p_tile, G = g.p_split;
     const int cin = g.cin, cout = g.cout, K = g.K;
     const int nch = cin / (16 * KC);
@@ -200,6 +209,7 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
 #pragma unroll
         for (int c = 0; c < NC; ++c) slab[(long)row * LDW + 16 * c + r] = 0.f;
     if constexpr (XF != 0) __syncthreads();
+    URN_STAMP(1);
 
     // pair word of block b for lane (r, q): pair r of the block = input row | row in the tile << 24.  With the weights as
     // the MFMA's A operand and the gathered rows as its B operand, lane (r, q) ends up with output columns 4q..4q+3 of
@@ -368,8 +378,10 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             t_c = t_n; tv_n = tv_nn; tv_nn = tv_n3;
         }
     }
+    URN_STAMP(2);
     if (g.dbg & 64) return;
     __syncthreads();
+    URN_STAMP(3);
 
     // epilogue: wave (cg, gi) finishes columns [col0, col0 + 16 NC) of the rows gi, gi + G, ... in groups of 4 (q)
     double s0[NC], s1[NC];
@@ -423,6 +435,7 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
             }
         }
     }
+    URN_STAMP(4);
     if (g.epi == 0) return;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
