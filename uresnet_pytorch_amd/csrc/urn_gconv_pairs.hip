@@ -383,67 +383,67 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_
     __syncthreads();
     URN_STAMP(3);
 
-    // epilogue: wave (cg, gi) finishes columns [col0, col0 + 16 NC) of the rows gi, gi + G, ... in groups of 4 (q)
-    double s0[NC], s1[NC];
-    float esc[NC], esh[NC], emu[NC], eis[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        s0[c] = 0.0; s1[c] = 0.0;
-        esc[c] = esh[c] = emu[c] = eis[c] = 0.f;
-        if (g.epi == 2) {
-            const int col = col0 + 16 * c + r;
-            esc[c] = g.e_scale[col]; esh[c] = g.e_shift[col]; emu[c] = g.e_mean[col]; eis[c] = g.e_invstd[col];
-        }
+    // epilogue: wave (cg, gi) finishes columns [col0, col0 + 16 NC) of the row groups gi, gi + G, ...  A lane owns FOUR
+    // consecutive columns of a row (16-byte slab reads, residual / BatchNorm-input loads and stores; one float per lane made
+    // the epilogue 2-3 us of a 12-25 us launch): 4 NC lanes per row, 64 / (4 NC) rows per wave instruction.
+    constexpr int LPR = 4 * NC, RPI = 64 / LPR;
+    const int c4 = lane % LPR, rl = lane / LPR;
+    const int lcol = lcol0 + 4 * c4, gcol = col0 + 4 * c4;
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 esc = (f32x4){0.f, 0.f, 0.f, 0.f}, esh = esc, emu = esc, eis = esc;
+    if (g.epi == 2) {
+        esc = *(const f32x4 *)(g.e_scale + gcol); esh = *(const f32x4 *)(g.e_shift + gcol);
+        emu = *(const f32x4 *)(g.e_mean + gcol); eis = *(const f32x4 *)(g.e_invstd + gcol);
     }
-    // four row groups per pass: their residual / BatchNorm-input elements are requested together before the first is used
-    // (one request per loop iteration made every iteration a round trip: 4 at T = 64, G = 4)
-    for (int lr0 = 4 * gi + q; lr0 < rows_here; lr0 += 16 * G) {
-        float rv[4][NC], xg[4][NC];
+    // two row groups per pass: their residual / BatchNorm-input elements are requested together before the first is used
+    // (four per pass pushed every instantiation to the 128-VGPR cap: 2.82 -> 3.14 ms per step)
+#pragma unroll 1
+    for (int lr0 = gi * RPI + rl; lr0 < rows_here; lr0 += 2 * G * RPI) {
+        f32x4 rv[2], xg[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int lr = lr0 + 4 * G * u;
+        for (int u = 0; u < 2; ++u) {
+            const int lr = lr0 + G * RPI * u;
             const long row = row0 + lr;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int col = col0 + 16 * c + r;
-                rv[u][c] = (g.res && lr < rows_here) ? g.res[row * cout + col] : 0.f;
-                xg[u][c] = (g.epi == 2 && lr < rows_here) ? g.e_x[row * cout + col] : 0.f;
-            }
+            rv[u] = (g.res && lr < rows_here) ? *(const f32x4 *)(g.res + row * cout + gcol) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            xg[u] = (g.epi == 2 && lr < rows_here) ? *(const f32x4 *)(g.e_x + row * cout + gcol) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int lr = lr0 + 4 * G * u;
+        for (int u = 0; u < 2; ++u) {
+            const int lr = lr0 + G * RPI * u;
             if (lr >= rows_here) break;
             const long row = row0 + lr;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int k = 0; k < G; ++k) v += *(const f32x4 *)(s_slab + (long)k * slab_words + (long)lr * LDW + lcol);
+            v += rv[u];
+            if (g.epi == 1) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int col = col0 + 16 * c + r;
-                float v = 0.f;
-                for (int k = 0; k < G; ++k) v += s_slab[(long)k * slab_words + (long)lr * LDW + (col - colw)];
-                v += rv[u][c];
-                if (g.epi == 1) {
-                    s0[c] += (double)v;
-                    s1[c] += (double)v * (double)v;
-                } else if (g.epi == 2) {
-                    const float xv = xg[u][c];
-                    if (!(fmaf(xv, esc[c], esh[c]) > 0.f)) v = 0.f;
-                    const double xh = ((double)xv - (double)emu[c]) * (double)eis[c];
-                    s0[c] += (double)v;
-                    s1[c] += (double)v * xh;
+                for (int k = 0; k < 4; ++k) { s0[k] += (double)v[k]; s1[k] += (double)v[k] * (double)v[k]; }
+            } else if (g.epi == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xv = xg[u][k];
+                    if (!(fmaf(xv, esc[k], esh[k]) > 0.f)) v[k] = 0.f;
+                    const double xh = ((double)xv - (double)emu[k]) * (double)eis[k];
+                    s0[k] += (double)v[k];
+                    s1[k] += (double)v[k] * xh;
                 }
-                g.y[row * g.ldy + col] = v;
             }
+            *(f32x4 *)(g.y + row * g.ldy + gcol) = v;
         }
     }
     URN_STAMP(4);
     if (g.epi == 0) return;
+    // lanes with the same four columns are LPR apart
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        s0[c] += __shfl_xor(s0[c], 16); s1[c] += __shfl_xor(s1[c], 16);
-        s0[c] += __shfl_xor(s0[c], 32); s1[c] += __shfl_xor(s1[c], 32);
-        if (q == 0) {
-            s_p[(long)(0 * G + gi) * cw + lcol0 + 16 * c + r] = s0[c];
-            s_p[(long)(1 * G + gi) * cw + lcol0 + 16 * c + r] = s1[c];
+    for (int m = LPR; m < 64; m <<= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += __shfl_xor(s0[k], m); s1[k] += __shfl_xor(s1[k], m); }
+    if (lane < LPR) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s_p[(long)(0 * G + gi) * cw + lcol + k] = s0[k];
+            s_p[(long)(1 * G + gi) * cw + lcol + k] = s1[k];
         }
     }
     __syncthreads();
@@ -490,6 +490,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
 {
     const int T = a.p_tile;
     if ((T != 32 && T != 64 && T != 128) || a.cin % 16 || a.cout % 16 || a.K > 27) return 0;
+    if (a.ldy % 4 || ((uintptr_t)a.y & 15) || (a.res && ((uintptr_t)a.res & 15)) || (a.e_x && ((uintptr_t)a.e_x & 15))) return 0;   // 16-byte epilogue accesses
     const int ks = a.cin / 16, nblk = a.cout / 16;
     int kc = 1;
     for (int d : {8, 6, 5, 4, 3, 2})
