@@ -122,7 +122,7 @@ extern "C" int urn_pairs_build(int n_tables, const int32_t *const *tbl, const in
 // KC: 16-channel groups per contraction chunk (cin = 16 * KC * nch); NC: 16-column blocks per wave; XF: rows are used as
 // relu(x * scale + shift) (folded BatchNorm+ReLU of the input)
 template <int KC, int NC, int XF, int DEEP>
-__global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512) void k_gconv_pairs(GArgs g)
+__global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && NC == 1 && DEEP == 0) ? 5 : 1) void k_gconv_pairs(GArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // diagnostics, compiled only with -DURN_PAIRS_STAMP (make CXXFLAGS+=...): s_memtime at the phase boundaries of every wave
