@@ -11,7 +11,7 @@ from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
 from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
 L = L_.load(); dev = torch.device('cuda:0')
 DEFAULTS = {'pairs_waves': 2560, 'pairs_wgs': 512, 'dw_blocks': 768, 'pairs_deep': 2, 'pairs_max_cin': 80, 'pairs_max_cout': 999,
-            'pairs_nc': 0, 'pairs_split': 0, 'pairs_cbg': 0, 'dw_split': 2, 'dw_2stage': 0}
+            'pairs_nc': 0, 'pairs_split': 0, 'pairs_split_kc1': 0, 'pairs_split_kc2': 0, 'pairs_split_kc3': 0, 'pairs_split_kc4': 0, 'pairs_split_kc5': 0, 'pairs_cbg': 0, 'dw_split': 2, 'dw_2stage': 0}
 flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=5, SPATIAL_SIZE=512, NUM_CLASS=5)
 torch.manual_seed(0)
 model = SparseUResNet(flags).to(dev).train(); crit = SparseSegmentationLoss(flags)
@@ -25,12 +25,24 @@ def run(n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-policies = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in a.split(',') if kv) for a in sys.argv[1:]] or [{}]
+def parse(a):
+    d = {}
+    for kv in a.split(','):
+        if not kv: continue
+        k, v = kv.split('=')
+        d[k] = v if k.startswith('tiles_') else int(v)     # tiles_nbr=64/64/64/128/64: rows per tile of the pair lists, per level
+    return d
+policies = [parse(a) for a in sys.argv[1:]] or [{}]
 res = [[] for _ in policies]
 for rnd in range(5):
     for i, pol in enumerate(policies):
         for k, v in DEFAULTS.items(): L.urn_set_option(k.encode(), v)
+        from uresnet_pytorch_amd import sparse_ops as so
+        so.SparseGeometry.PAIRS_TILES = {'nbr': [64], 'chd': [64], 'up': [128]}
         for k, v in pol.items():
+            if k.startswith('tiles_'):
+                so.SparseGeometry.PAIRS_TILES[k[6:]] = [int(t) for t in v.split('/')]
+                continue
             assert L.urn_set_option(k.encode(), v) == 0, k
         res[i].append(run())
 for a, r in zip(sys.argv[1:], res):

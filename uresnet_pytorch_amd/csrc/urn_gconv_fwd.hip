@@ -318,6 +318,7 @@ static long long *g_opt_stamps = nullptr;
 static const int g_opt_fin_in_kernel = 0;   // (the in-kernel finalize lived in the removed 64x16 LDS kernel)
 static int g_opt_pipe = 0;
 static int g_opt_kernel = 7;   // 7 = compacted rule lists when the call carries them (urn_gconv_pairs.hip), else the 2-D tile; 6 = 2-D workgroup tile (urn_gconv_tile.hip); 3 = register gather (fallback for shapes without a tile instantiation)
+extern int g_pairs_split_kc[9];
 extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs, g_dwp_waves, g_dwp_smax, g_dwp_dbg, g_dwp_cap;
 // which calls that carry a pair list run on the pair-list kernel (measured per shape on the cfg3 geometry, tools/bench_pairs.py:
 // it wins for the strided pair and the narrow levels; the wide, small levels are faster on the LDS-staged 2-D tile kernel):
@@ -334,6 +335,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "gconv_pipe")) { g_opt_pipe = value != 0; return URN_OK; }
     if (!strcmp(key, "gconv_min_waves")) { g_opt_min_waves = value; return URN_OK; }
     if (!strcmp(key, "gconv_kernel")) { g_opt_kernel = (int)value; return URN_OK; }
+    if (!strncmp(key, "pairs_split_kc", 14) && key[14] >= '1' && key[14] <= '8' && !key[15]) { g_pairs_split_kc[key[14] - '0'] = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_waves")) { g_pairs_waves = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_frag_wide")) { g_pairs_frag_wide = value != 0; return URN_OK; }
     if (!strcmp(key, "pairs_max_cin")) { g_pairs_max_cin = (int)value; return URN_OK; }

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
 int g_pairs_waves = 2560;    // a launch is split G ways until it has about this many waves (urn_set_option "pairs_waves"): alone more is faster (4096+), beside the weight gradients of the training step fewer are (A/B in one process, tools/ab_options.py: 3.21 ms per step at 4096, 3.12 at 3072, 3.06 at 2560, 3.09 at 2304, 3.12 at 2048, 3.19 at 1536)
 int g_pairs_nc = 0;          // force the column blocks per wave (urn_set_option "pairs_nc"), 0 = automatic
 int g_pairs_split = 0;
+int g_pairs_split_kc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // force G for inputs of 16 KC channels (urn_set_option "pairs_split_kc<KC>"), 0 = automatic
 int g_pairs_wgs = 512;       // a workgroup takes several column groups only while the launch keeps this many workgroups ("pairs_wgs")
 int g_pairs_deep = 2;        // bit KC set: three rotating row-register sets for inputs of 16 KC channels (KC <= 3; urn_set_option "pairs_deep")
 int g_pairs_cbg = 0;          // most column groups per workgroup (urn_set_option "pairs_cbg"), 0 = as many as fit       // force G (urn_set_option "pairs_split"), 0 = automatic
@@ -519,6 +520,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     int G = 1;
     while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < g_pairs_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= 65536) ++G;
     if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= 65536) G = g_pairs_split;
+    if (kc <= 8 && g_pairs_split_kc[kc] > 0 && cbg * g_pairs_split_kc[kc] <= maxw && lds_bytes(g_pairs_split_kc[kc]) <= 65536) G = g_pairs_split_kc[kc];
     if (lds_bytes(G) > 65536) return 0;
     a.p_split = G; a.p_cw = cw; a.p_deep = ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1;   // bit KC of the option
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
