@@ -46,6 +46,7 @@ struct DenseArgs {
     float *slab;                                    // split > 1: partial outputs [z][sub-grid row][cout] instead of y
     int ntaps;
     int tap_w[27], tap_box[27];                     // per tap: weight tap index, offset of the tap inside the staged box (voxels)
+    long long *stamps;                              // diagnostics (-DURN_DENSE_STAMP, urn_set_option "dense_stamp_ptr")
     double *stats;                                  // optional [stat_slots][2][cout]: column sums / sums of squares of y ADDED (fp64 atomics)
     int stat_slots;
 };
@@ -303,6 +304,13 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
     unsigned char *s_box = smem_raw;
     unsigned char *s_w = smem_raw + ((NBOX * ROWB + 15) & ~15);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef URN_DENSE_STAMP
+    long long *stamp = g.stamps ? g.stamps + (((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 : nullptr;
+#define URN_DSTAMP(i) do { if (stamp && lane == 0) stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define URN_DSTAMP(i) do { } while (0)
+#endif
+    URN_DSTAMP(0);
     const int r = lane & 15, q = lane >> 4;
     const int tiles_x = (g.Sub[2] + 15) / 16, tiles_y = (g.Sub[1] + 3) / 4, tiles_z = (g.Sub[0] + 3) / 4;
     int t = blockIdx.x;
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
                 }
             }
         }
+        URN_DSTAMP(1);
 #pragma unroll
         for (int jz = 0; jz < 3; ++jz) {
             if (jz < jz_lo || jz >= jz_hi) continue;       // workgroup-uniform
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
                 }
             }
             __syncthreads();
+            if (jz == 0) URN_DSTAMP(2);
 #pragma unroll
             for (int jy = 0; jy < 3; ++jy)
 #pragma unroll
@@ -441,6 +451,7 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
                 }
         }
     }
+    URN_DSTAMP(3);
     const bool split = g.slab != nullptr;
     const bool stats = g.stats != nullptr && !split;
     double d0[NCB], d1[NCB];
@@ -471,6 +482,7 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
             }
         }
     }
+    URN_DSTAMP(4);
     if (stats) dense_stats_flush<NCB>(d0, d1, 0, NCB, NCOLS, col_w0, g.cout, g.stats, g.stat_slots, blockIdx.x, smem_raw);
 }
 
@@ -541,6 +553,8 @@ __global__ __launch_bounds__(256) void k_dense_splitk_reduce(DenseArgs g, int Z)
     }
 }
 
+long long *g_dense_stamps = nullptr;   // diagnostics (urn_set_option "dense_stamp_ptr"; kernels built with -DURN_DENSE_STAMP)
+
 // split factor of a launch: only when the output tiles alone leave most CUs idle
 static void dense_plan_split(long wgs, int nchunks, int ntaps, int &zc, int &zt)
 {
@@ -575,7 +589,7 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
     DenseArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.ldx = (long)ldx; a.ldy = (long)ldy; a.cin = cin; a.cout = cout; a.B = batch;
-    a.mode = gm->mode; a.stats = stats; a.stat_slots = stat_slots;
+    a.mode = gm->mode; a.stats = stats; a.stat_slots = stat_slots; a.stamps = g_dense_stamps;
     for (int d = 0; d < 3; ++d) {
         a.In[d] = gm->In[d]; a.Out[d] = gm->Out[d]; a.Sub[d] = gm->Sub[d]; a.p[d] = gm->p[d]; a.os[d] = gm->os[d]; a.s[d] = gm->s[d];
         a.nt[d] = gm->nt[d]; a.kdim[d] = gm->kdim[d];
