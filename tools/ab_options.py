@@ -15,7 +15,7 @@ DEFAULTS = {'pairs_waves': 2560, 'pairs_wgs': 512, 'dw_blocks': 768, 'pairs_deep
 flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=5, SPATIAL_SIZE=512, NUM_CLASS=5)
 torch.manual_seed(0)
 model = SparseUResNet(flags).to(dev).train(); crit = SparseSegmentationLoss(flags)
-blob = make_sparse_blob([0], 512, 50000)
+blob = make_sparse_blob(list(range(int(os.environ.get('EVENTS', '1')))), 512, 50000)   # EVENTS=2: two events per GPU
 data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
 grads = parallel.FlatGradients(model); opt = parallel.FlatAdam(grads, lr=1e-3)
 def step():
