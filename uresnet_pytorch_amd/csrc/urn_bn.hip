@@ -471,7 +471,7 @@ extern "C" int urn_bn_bwd_apply(const float *x, const float *g, const float *ext
 // bn_bwd_apply with the two coefficients taken from an accumulated slab ([slots][2][c], gather-conv epilogue 2 with
 // part_slots): every block first reduces the slots into LDS, then streams its share of the elements.  Block 0
 // accumulates dgamma/dbeta.  EPB elements per block so that the slab re-read stays small beside the stream.
-#define URN_APPLY_EPB 2048
+#define URN_APPLY_EPB 1024
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_sums(const float *__restrict__ x, const float *__restrict__ g,
                                                            const float *__restrict__ extra, long ld_extra, long total, int c,
                                                            const float *__restrict__ gamma,
