@@ -516,7 +516,12 @@ static void dw2_plan(int K, int64_t n_out, int cin, int cout, int &chunks, long 
     // aim for ~2048 blocks, chunks of at least 256 rows (multiple of 256)
     // (the tuned target holds up to ~100k rows; launches over larger levels own more of the chip: 4 events per GPU
     // measured 9.5 ms per step with 2048 against 10.0 with 1152)
-    const int dw_target = n_out >= 150000 && g_dw_blocks < 2048 ? 2048 : g_dw_blocks;
+    // ... and more of them for bigger launches (rows x cin x cout; every cfg3 launch is under 40 M): 2 and 4 events per GPU and
+    // the cfg5 shapes (768^3, 200k voxels, uf 32) like 1152-1536 (cfg5 fp16 step 22.0 -> 21.0 ms, fp32 29.6 -> 27.9)
+    const double work = (double)n_out * cin * cout;
+    int dw_target = g_dw_blocks;
+    if (g_dw_blocks == 768) dw_target = work < 40e6 ? 768 : (work < 160e6 ? 1152 : 1536);
+    if (n_out >= 150000 && dw_target < 2048) dw_target = 2048;
     chunks = dw_target / (K * n_ci_tiles * n_co_tiles);
     if (chunks < 1) chunks = 1;
     chunk = (n_out + chunks - 1) / chunks;
