@@ -32,3 +32,14 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 print('S=%d: %.1f ms per fwd+loss+bwd step, %.2f M voxels/s, peak mem %.1f GB' % (S, dt * 1e3, S ** 3 / dt / 1e6, torch.cuda.max_memory_allocated() / 1e9))
+
+# optional: the same step replayed from a captured graph (uresnet_pytorch_amd/graphed.py)
+if os.environ.get('URN_GRAPH'):
+    from uresnet_pytorch_amd.graphed import GraphedDenseStep
+    gs = GraphedDenseStep(net, crit, data, label)
+    gs(data, label); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5): gl, _ = gs(data, label)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print('graph replay: %.1f ms per step, %.2f M voxels/s, loss %.4f' % (dt * 1e3, S ** 3 / dt / 1e6, float(gl)))
