@@ -24,6 +24,7 @@
 #include <string.h>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define URN_PAIRS_IDXB 24   // blocks per chunk of the wave-private pair-word strip in LDS (DEEP variants)
 
 // ------------------------------------------------------------------------------------------------ list builder
 #define URN_PAIRS_MAX_TABLES 16
@@ -262,17 +263,12 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
         // at the unpipelined gather rate: 3 wave-loads/us against 20 with four in flight, tools/ubench/gather_rate.hip).
         // The loop is unrolled by three so that no register set is ever copied (a copy of a register with a pending load
         // waits for it); the pair words arrive in triples, two triples ahead of their use.
+        // The pair words of a wave's share are first copied into a wave-private LDS strip (chunks of IDXB blocks) and read
+        // from there: they then do not sit in the vector-memory queue between the row loads, whose waits (s_waitcnt
+        // vmcnt(N), in issue order) can leave the younger rows in flight.
         if (b0 < b1) {
             f32x4 A0[KC], A1[KC], A2[KC];
-            int pP[3], tP[3], pQ[3], tQ[3], pR[3], tR[3];
-            auto idx3 = [&](int b, int (&pv)[3], int (&tv)[3]) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) load_idx(b + k < b1 ? b + k : b1 - 1, pv[k], tv[k]);
-            };
-            idx3(b0, pP, tP);
-            idx3(b0 + 3, pQ, tQ);
-            load_a(A0, pP[0], 0);
-            load_a(A1, pP[1], 0);
+            int *my_idx = (int *)(s_p + 2 * (long)G * cw) + (long)wave * (URN_PAIRS_IDXB * 17);
             int w_key = -1;
             // one block: slab rows of pair word pv / offset tv from `use`; the rows of the block two ahead go into `ld`
             auto step = [&](f32x4 (&use)[KC], f32x4 (&ld)[KC], int pv, int tv, int pv_ld) {
@@ -308,13 +304,19 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
 #pragma unroll
                 for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = old[c] + (acc[c] + acc2[c]);
             };
-            for (int b = b0; b < b1; b += 3) {
-                idx3(b + 6, pR, tR);
-                step(A0, A2, pP[0], tP[0], pP[2]);
-                if (b + 1 < b1) step(A1, A0, pP[1], tP[1], pQ[0]);
-                if (b + 2 < b1) step(A2, A1, pP[2], tP[2], pQ[1]);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { pP[k] = pQ[k]; tP[k] = tQ[k]; pQ[k] = pR[k]; tQ[k] = tR[k]; }
+            for (int c0 = b0; c0 < b1; c0 += URN_PAIRS_IDXB) {
+                const int c1 = c0 + URN_PAIRS_IDXB < b1 ? c0 + URN_PAIRS_IDXB : b1, nbk = c1 - c0;
+                for (int i = lane; i < nbk * 16; i += 64) my_idx[i] = blk_p[(long)c0 * 16 + i];
+                for (int i = lane; i < nbk; i += 64) my_idx[URN_PAIRS_IDXB * 16 + i] = blk_t[c0 + i];
+                auto PV = [&](int b) { return my_idx[((b < c1 ? b : c1 - 1) - c0) * 16 + r]; };
+                auto TV = [&](int b) { return my_idx[URN_PAIRS_IDXB * 16 + (b - c0)]; };
+                load_a(A0, PV(c0), 0);
+                load_a(A1, PV(c0 + 1), 0);
+                for (int b = c0; b < c1; b += 3) {
+                    step(A0, A2, PV(b), TV(b), PV(b + 2));
+                    if (b + 1 < c1) step(A1, A0, PV(b + 1), TV(b + 1), PV(b + 3));
+                    if (b + 2 < c1) step(A2, A1, PV(b + 2), TV(b + 2), PV(b + 4));
+                }
             }
         }
     }
@@ -513,16 +515,17 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
         if (cbg_all % d == 0 && (d == 1 || ntiles * (cbg_all / d) >= g_pairs_wgs)) { cbg = d; break; }
     if (g_pairs_cbg > 0 && cbg_all % g_pairs_cbg == 0 && g_pairs_cbg <= maxw) cbg = g_pairs_cbg;
     const int gy = cbg_all / cbg, cw = 16 * nc * cbg;
+    const bool deep = ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1 && kc <= 3 && a.pairs != nullptr;
     auto lds_bytes = [&](int G) {
         size_t w = (size_t)2 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
-        return w * 4 + (size_t)2 * G * cw * 8;
+        return w * 4 + (size_t)2 * G * cw * 8 + (deep ? (size_t)cbg * G * URN_PAIRS_IDXB * 17 * 4 : 0);
     };
     int G = 1;
     while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < g_pairs_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= 65536) ++G;
     if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= 65536) G = g_pairs_split;
     if (kc <= 8 && g_pairs_split_kc[kc] > 0 && cbg * g_pairs_split_kc[kc] <= maxw && lds_bytes(g_pairs_split_kc[kc]) <= 65536) G = g_pairs_split_kc[kc];
     if (lds_bytes(G) > 65536) return 0;
-    a.p_split = G; a.p_cw = cw; a.p_deep = ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1;   // bit KC of the option
+    a.p_split = G; a.p_cw = cw; a.p_deep = deep;   // bit KC of the option
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
     const size_t lds = lds_bytes(G);
 #define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs2<KCv, NCv>(a, grid, block, lds, st); return (int)ntiles; }
