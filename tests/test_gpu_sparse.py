@@ -805,3 +805,16 @@ def test_side_stream_handles_are_capped(dev, monkeypatch):
     del nets
     gc.collect()
     assert trunk._SIDE_HANDLES == base
+
+
+def test_many_geometries_with_deferred_count_readback(dev):
+    """the level counts travel through a ring of 16 pinned host buffers: a geometry whose slot has been handed out again
+    before its sync() must still report its own counts"""
+    from uresnet_pytorch_amd import sparse_ops as so
+    geos = []
+    for s in range(40):
+        b = make_sparse_blob([s], 64, 500 + 10 * s)
+        geos.append(so.SparseGeometry(torch.from_numpy(b['data'][:, :4].astype(np.int32)).to(dev), 64, 3, defer_sync=True))
+    for g in geos:
+        g.sync()
+        assert g.n == g.counts.cpu().tolist()[:3]

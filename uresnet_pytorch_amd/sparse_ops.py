@@ -119,6 +119,7 @@ class SparseGeometry:
         # and the host's first float-phase launches are not exposed (kernel trace before: 35 us idle at the blocking
         # copy + 34 us until the next launch arrived, per step).
         self._n_host = _pinned_counts(nl)
+        self._n_gen = _PINNED_NEXT                 # (the ring slot is ours until 16 more geometries have been built)
         self._n_host.copy_(self.counts[:nl], non_blocking=True)
         self._n_event = torch.cuda.Event()
         self._n_event.record(torch.cuda.current_stream(dev))
@@ -180,6 +181,9 @@ class SparseGeometry:
         """the one host synchronisation of the integer phase: per-level site counts"""
         if self.n is None:
             if os.environ.get('URN_LATE_COUNTS'):     # A/B: the blocking copy at the end of the integer phase
+                self.n = self.counts.cpu().tolist()[:self.num_levels]
+                return self
+            if _PINNED_NEXT - self._n_gen >= 16:     # our ring slot was handed out again: read the device copy instead
                 self.n = self.counts.cpu().tolist()[:self.num_levels]
                 return self
             self._n_event.synchronize()
