@@ -36,6 +36,9 @@ class GraphedDenseStep(object):
         # the gradient tensors the graph writes (its private pool): re-attached after every replay, whatever happened to
         # p.grad in between (an eager step, zero_grad(set_to_none=True))
         self.grads = [(p, p.grad) for p in self.net.parameters() if p.grad is not None]
+        # buffers of the library's module-level caches that the captured launches address: kept alive with the graph
+        from . import dense_conv as _dc
+        self._keep = (_dc._POOL.buf, dict(_dc._SCRATCH))
 
     def _step(self):
         self.net.zero_grad(set_to_none=True)
