@@ -336,10 +336,13 @@ int64_t urn_dense_conv_scratch_bytes(int cout, int batch, const urn_dense_geom *
  * outputs it writes (fp64 atomics from the epilogue, workgroup % stat_slots picks the row) -- the batch statistics of the
  * BatchNorm that follows every convolution of the model without a pass over y; several calls (the parity classes of a
  * transposed conv) accumulate into one slab; urn_bn_finalize_fwd(stats, stat_slots, ...) turns it into mean / invstd /
- * scale / shift.  Needs 256 % (cout / 4) == 0. */
+ * scale / shift.  Needs 256 % (cout / 4) == 0.
+ * xf_scale / xf_shift (cin each, may be NULL): the input is used as x * scale + shift -- the BatchNorm of the producing
+ * convolution folded into this one's load (reference uresnet_dense.py:78-81: no ReLU between residual1 and residual2); the
+ * normalised tensor then never exists in HBM.  urn_dense_dw takes the same pair for its x operand. */
 int urn_dense_conv(const float *x, int64_t ldx, int cin, const float *wt, const float *bias, float *y, int64_t ldy, int cout,
-                   int batch, const urn_dense_geom *geom, int precision, double *stats, int stat_slots, void *scratch,
-                   int64_t scratch_bytes, void *stream);
+                   int batch, const urn_dense_geom *geom, int precision, double *stats, int stat_slots, const float *xf_scale,
+                   const float *xf_shift, void *scratch, int64_t scratch_bytes, void *stream);
 /* Gradient of F.pad(mode='replicate') (reference uresnet_dense.py:75-80): dx[i] = sum of dxp over the padded positions
  * that clamp to voxel i.  dxp: rows of the padded volume (dims + pad_lo + pad_hi), dx: rows of the volume; c % 4 == 0. */
 /* Weight gradient of the same convolutions: dw[tap][ci][co] (+)= sum over outputs o of x[in(o, tap)][ci] * dy[o][co] with
@@ -352,7 +355,8 @@ int urn_dense_conv(const float *x, int64_t ldx, int cin, const float *wt, const 
 int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, const int *k, int cin, int cout);
 int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *dy, int64_t ld_dy, int cout, int batch, const int *in_dims,
                  const int *out_dims, const int *k, const int *s, const int *lo, int mode, float *dw, int dw_layout, int cin_valid,
-                 int cout_valid, void *scratch, int64_t scratch_bytes, int precision, void *stream);
+                 int cout_valid, const float *xf_scale, const float *xf_shift, void *scratch, int64_t scratch_bytes, int precision,
+                 void *stream);
 int urn_dense_fold(const float *dxp, float *dx, int batch, const int *dims, const int *pad_lo, const int *pad_hi, int c,
                    void *stream);
 /* Row passes around the convolutions (reference uresnet_dense.py:72-83: conv -> BatchNorm(batch statistics) [-> + shortcut]

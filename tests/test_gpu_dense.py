@@ -243,3 +243,38 @@ def test_dense_step_replayed_from_a_graph_gives_the_eager_gradients(dev):
         assert set(got) == set(ref)
         for k in ref:
             assert rel(got[k], ref[k]) < 1e-6, k
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 1e-5), ('bf16', 1e-2)])
+@pytest.mark.parametrize('dim,spatial,cin,cout,k,stride', [(3, (16, 16, 16), 16, 16, 3, 1), (3, (8, 12, 16), 32, 32, 3, 1), (3, (8, 8, 8), 16, 32, 3, 2),
+                                                        (2, (20, 12), 8, 16, 3, 1), (3, (8, 8, 8), 64, 64, 1, 1)])
+def test_dense_conv_with_folded_input_affine(dev, dim, spatial, cin, cout, k, stride, prec, tol):
+    """xf = (scale, shift): the convolution and its weight gradient use x * scale + shift (the producer's BatchNorm folded into
+    the load, urn_dense_conv / urn_dense_dw); the input gradient is the one w.r.t. that affine image (BNFoldFunction takes it
+    through the BatchNorm).  Against torch on the CPU."""
+    from uresnet_pytorch_amd import dense_conv as dc
+    dc.set_precision(prec)
+    try:
+        B = 2
+        g = torch.Generator().manual_seed(3 * cin + cout)
+        x = torch.randn(B, cin, *spatial, generator=g)
+        w = torch.randn(cout, cin, *([k] * dim), generator=g) / (cin * k ** dim) ** 0.5
+        b = torch.randn(cout, generator=g)
+        sc = torch.rand(cin, generator=g) + 0.5; sh = torch.randn(cin, generator=g)
+        lo, hi = ref_padding(k, stride, spatial[-1])
+        shape = (1, cin) + (1,) * dim
+        u = (x * sc.view(shape) + sh.view(shape)).requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        up = F.pad(u, (lo, hi) * dim, mode='replicate') if (lo or hi) else u
+        y_ref = (F.conv3d if dim == 3 else F.conv2d)(up, wr, b, stride=stride)
+        dy = torch.randn(y_ref.shape, generator=g)
+        y_ref.backward(dy)
+        rows = to_rows(x).to(dev).requires_grad_(True)
+        wg = w.to(dev).requires_grad_(True)
+        y = dc.DenseConvFunction.apply(rows, wg, b.to(dev), B, spatial, stride, lo, hi, None, True, (sc.to(dev), sh.to(dev)))
+        y.backward(to_rows(dy).to(dev))
+        assert rel(y, to_rows(y_ref)) < tol
+        assert rel(rows.grad, to_rows(u.grad)) < tol          # gradient w.r.t. the affine image
+        assert rel(wg.grad, wr.grad) < tol
+    finally:
+        dc.set_precision('fp32')

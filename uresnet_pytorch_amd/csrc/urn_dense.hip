@@ -28,6 +28,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct DenseArgs {
     const float *x, *wt, *bias;
+    const float *xf_scale, *xf_shift;               // optional (cin): x is used as x * scale + shift
     float *y;
     long ldx, ldy;
     int cin, cout;
@@ -78,6 +79,18 @@ __device__ __forceinline__ void dense_stats_flush(double (&d0)[MAXCB], double (&
         const int which = e >= ncols ? 1 : 0, col = e - which * ncols;
         unsafeAtomicAdd(&stats[(slot * 2 + which) * cout + col_w0 + col], s_red[e]);
     }
+}
+
+// the producing layer's BatchNorm folded into the consumer's load (reference uresnet_dense.py:78-81: residual1's BatchNorm
+// output feeds residual2's convolution with no ReLU between them): x * scale + shift per channel while the box is staged
+__device__ __forceinline__ f32x4 dense_xf(f32x4 v, const float *__restrict__ sc, const float *__restrict__ sh, int c)
+{
+    if (sc) {
+        const f32x4 a = *(const f32x4 *)(sc + c), b = *(const f32x4 *)(sh + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], a[k], b[k]);
+    }
+    return v;
 }
 
 __device__ __forceinline__ unsigned short f2bf(float f)
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(512) void k_dense_conv(DenseArgs g)
                     bool ok = okr;
                     if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
                     else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
-                    f32x4 val = *(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4);
+                    f32x4 val = dense_xf(*(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4), g.xf_scale, g.xf_shift, ch0 + 4 * k4);
                     if (!ok) val = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if constexpr (PREC) {
                         uint2 pk;
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
                     if (h0 + it < NIT && f < TOT_E) {
                         const int rowi = f / ROW_E, e = f - rowi * ROW_E;
                         const int bx = e >> PER_LOG, k4 = e & (PER - 1);
-                        f32x4 v = val[it];
+                        f32x4 v = dense_xf(val[it], g.xf_scale, g.xf_shift, ch0 + 4 * k4);
                         if (!okv[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                         unsigned char *dst = s_box + (rowi * BX + bx) * ROWB;
                         if constexpr (PREC) {
@@ -580,8 +593,9 @@ extern "C" int64_t urn_dense_conv_scratch_bytes(int cout, int batch, const urn_d
 
 extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float *wt, const float *bias, float *y, int64_t ldy,
                               int cout, int batch, const urn_dense_geom *gm, int precision, double *stats, int stat_slots,
-                              void *scratch, int64_t scratch_bytes, void *stream)
+                              const float *xf_scale, const float *xf_shift, void *scratch, int64_t scratch_bytes, void *stream)
 {
+    URN_CHECK_ARG((xf_scale == nullptr) == (xf_shift == nullptr), "scale and shift go together");
     URN_CHECK_ARG(x && wt && y && gm, "null pointer");
     URN_CHECK_ARG(!stats || (stat_slots > 0 && 256 % (cout / 4) == 0), "statistics: slots > 0 and cout / 4 a divisor of 256");
     URN_CHECK_ARG(cin > 0 && cout > 0 && cin % 16 == 0 && cout % 16 == 0 && batch > 0, "channel counts must be multiples of 16");
@@ -589,7 +603,7 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
     DenseArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.ldx = (long)ldx; a.ldy = (long)ldy; a.cin = cin; a.cout = cout; a.B = batch;
-    a.mode = gm->mode; a.stats = stats; a.stat_slots = stat_slots; a.stamps = g_dense_stamps;
+    a.mode = gm->mode; a.stats = stats; a.stat_slots = stat_slots; a.stamps = g_dense_stamps; a.xf_scale = xf_scale; a.xf_shift = xf_shift;
     for (int d = 0; d < 3; ++d) {
         a.In[d] = gm->In[d]; a.Out[d] = gm->Out[d]; a.Sub[d] = gm->Sub[d]; a.p[d] = gm->p[d]; a.os[d] = gm->os[d]; a.s[d] = gm->s[d];
         a.nt[d] = gm->nt[d]; a.kdim[d] = gm->kdim[d];
@@ -777,6 +791,7 @@ extern "C" int urn_dense_fold(const float *dxp, float *dx, int batch, const int 
 // launch adds the shares in a fixed order (no atomics: bitwise reproducible).
 struct DenseDwArgs {
     const float *x, *dy;
+    const float *xf_scale, *xf_shift;   // optional (cin): x is used as x * scale + shift
     long ldx, ld_dy;
     int cin, cout, B;
     int In[3], Out[3], k[3], s[3], lo[3];
@@ -839,7 +854,7 @@ __global__ __launch_bounds__(512) void k_dense_dw(DenseDwArgs g)
                 if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
                 else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
                 f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok) val = *(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4);
+                if (ok) val = dense_xf(*(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4), g.xf_scale, g.xf_shift, ci0 + 4 * k4);
                 if constexpr (PREC) {
                     uint2 pk;
                     pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
@@ -996,7 +1011,7 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
                     if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
                     else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
                     f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (ok) val = *(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4);
+                    if (ok) val = dense_xf(*(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4), g.xf_scale, g.xf_shift, ci0 + 4 * k4);
                     if constexpr (PREC) {
                         uint2 pk;
                         pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
@@ -1144,9 +1159,10 @@ extern "C" int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, co
 
 extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *dy, int64_t ld_dy, int cout, int batch,
                             const int *in_dims, const int *out_dims, const int *k, const int *s, const int *lo, int mode,
-                            float *dw, int dw_layout, int cin_valid, int cout_valid, void *scratch, int64_t scratch_bytes,
-                            int precision, void *stream)
+                            float *dw, int dw_layout, int cin_valid, int cout_valid, const float *xf_scale, const float *xf_shift,
+                            void *scratch, int64_t scratch_bytes, int precision, void *stream)
 {
+    URN_CHECK_ARG((xf_scale == nullptr) == (xf_shift == nullptr), "scale and shift go together");
     URN_CHECK_ARG(x && dy && dw && scratch && in_dims && out_dims && k && s && lo, "null pointer");
     URN_CHECK_ARG(dw_layout == 0 || (dw_layout == 1 && cin_valid > 0 && cin_valid <= cin && cout_valid > 0 && cout_valid <= cout),
                   "dw_layout 0 ([tap][cin][cout], accumulated) or 1 (torch layout, written) with the valid channel counts");
@@ -1155,6 +1171,7 @@ extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *d
     DenseDwArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.dy = dy; a.ldx = (long)ldx; a.ld_dy = (long)ld_dy; a.cin = cin; a.cout = cout; a.B = batch; a.mode = mode;
+    a.xf_scale = xf_scale; a.xf_shift = xf_shift;
     int ntap = 1;
     for (int d = 0; d < 3; ++d) {
         a.In[d] = in_dims[d]; a.Out[d] = out_dims[d]; a.k[d] = k[d]; a.s[d] = s[d]; a.lo[d] = lo[d];

@@ -94,7 +94,7 @@ def stats_ok(c):
     return c % 4 == 0 and 256 % (c // 4) == 0 and 256 % (cp // 4) == 0
 
 
-def _launch(x, ldx, cin, wt, bias, y, ldy, cout, B, g, stats=None):
+def _launch(x, ldx, cin, wt, bias, y, ldy, cout, B, g, stats=None, xf=None):
     L = _l.load()
     sb = L.urn_dense_conv_scratch_bytes(cout, B, ctypes.byref(g))
     key = (x.device, sb > 256)
@@ -104,7 +104,8 @@ def _launch(x, ldx, cin, wt, bias, y, ldy, cout, B, g, stats=None):
         scratch = _SCRATCH[key] = torch.empty(max(sb, 256), dtype=torch.uint8, device=x.device)
     _l.check(L.urn_dense_conv(x.data_ptr(), ldx, cin, wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), ldy,
                               cout, B, ctypes.byref(g), PRECISION, None if stats is None else stats.data_ptr(),
-                              0 if stats is None else stats.shape[0], scratch.data_ptr(), scratch.numel(), _l.stream()), 'dense_conv')
+                              0 if stats is None else stats.shape[0], None if xf is None else xf[0].data_ptr(),
+                              None if xf is None else xf[1].data_ptr(), scratch.data_ptr(), scratch.numel(), _l.stream()), 'dense_conv')
 
 
 def _colsum(rows, c):
@@ -195,8 +196,10 @@ class DenseConvFunction(torch.autograd.Function):
     """y rows = Conv(k, stride) of the replicate-padded volume (+ bias).  rows: (B * prod(spatial), Cin)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, B, spatial, stride, pad_lo, pad_hi, stats=None, bias_grad=True):
-        """stats: zeroed new_stats(cout_p) slab to receive the column statistics of y (not differentiable);
+    def forward(ctx, rows, weight, bias, B, spatial, stride, pad_lo, pad_hi, stats=None, bias_grad=True, xf=None):
+        """xf = (scale, shift) of cin floats each (not differentiable here, see dense_hip.BNConvFunction): the rows are
+        used as rows * scale + shift (the producer's BatchNorm folded into this convolution's load).
+        stats: zeroed new_stats(cout_p) slab to receive the column statistics of y (not differentiable);
         bias_grad False: the bias feeds a batch-statistics BatchNorm, its gradient is identically zero (the sum of a
         BatchNorm's input gradient over the rows vanishes) and is returned as zeros without the column-sum pass"""
         _l.require_gpu(rows)
@@ -214,8 +217,13 @@ class DenseConvFunction(torch.autograd.Function):
         bias_p = None if bias is None else _pad16(bias.contiguous(), 0)
         n_out = B * Out[0] * Out[1] * Out[2]
         y = torch.empty((n_out, cout_p), dtype=torch.float32, device=rows.device)
-        _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, fwd, stats)
+        xfp = None
+        if xf is not None:        # padded channels: x = 0 there, scale 1 / shift 0 keeps them 0
+            xfp = (torch.cat([xf[0], xf[0].new_ones(cin_p - cin)]) if cin_p != cin else xf[0].contiguous(),
+                   torch.cat([xf[1], xf[1].new_zeros(cin_p - cin)]) if cin_p != cin else xf[1].contiguous())
+        _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, fwd, stats, xfp)
         ctx.save_for_backward(xin, weight)
+        ctx.xfp = xfp
         ctx.meta = (B, tuple(spatial), stride, Out, bwd, padinfo, cin, cout, cin_p, cout_p, bias is not None)
         ctx.bias_grad = bias_grad
         ctx.out_spatial = tuple(Out[3 - nd:])
@@ -246,13 +254,13 @@ class DenseConvFunction(torch.autograd.Function):
                 dxf = dxp
             dx = dxf[:, :cin].contiguous() if cin_p != cin else dxf
         if ctx.needs_input_grad[1]:
-            dw = dense_conv_dw(xin, dy, weight.shape, B, spatial, stride, lo, Out, cin, cout)
+            dw = dense_conv_dw(xin, dy, weight.shape, B, spatial, stride, lo, Out, cin, cout, ctx.xfp)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy, cout) if ctx.bias_grad else torch.zeros(cout, dtype=torch.float32, device=dy.device)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def _dw_call(x, cx, dy, cy, B, in_dims, out_dims, kk, ss, lo, mode, vx, vy, wshape):
+def _dw_call(x, cx, dy, cy, B, in_dims, out_dims, kk, ss, lo, mode, vx, vy, wshape, xf=None):
     """dw[tap][cx][cy] = sum_o x[in(o, tap)] (x) dy[o]  (two stages, deterministic), written in torch's parameter layout
     (vy, vx, taps) = wshape -- the zero-padded channels beyond vx / vy dropped"""
     L = _l.load()
@@ -261,11 +269,12 @@ def _dw_call(x, cx, dy, cy, B, in_dims, out_dims, kk, ss, lo, mode, vx, vy, wsha
     sb = L.urn_dense_dw_scratch_bytes(B, I3(*out_dims), I3(*kk), cx, cy)
     scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
     _l.check(L.urn_dense_dw(x.data_ptr(), cx, cx, dy.data_ptr(), cy, cy, B, I3(*in_dims), I3(*out_dims), I3(*kk), I3(*ss),
-                            I3(*lo), mode, dw.data_ptr(), 1, vx, vy, scratch.data_ptr(), sb, PRECISION, _l.stream()), 'dense_dw')
+                            I3(*lo), mode, dw.data_ptr(), 1, vx, vy, None if xf is None else xf[0].data_ptr(),
+                            None if xf is None else xf[1].data_ptr(), scratch.data_ptr(), sb, PRECISION, _l.stream()), 'dense_dw')
     return dw
 
 
-def dense_conv_dw(xin, dy, wshape, B, spatial, stride, lo, Out, cin, cout):
+def dense_conv_dw(xin, dy, wshape, B, spatial, stride, lo, Out, cin, cout, xf=None):
     """weight gradient of the padded convolution; xin (rows, cin_p), dy (rows_out, cout_p), both zero-padded to 16"""
     nd = len(spatial)
     k = wshape[2]
@@ -273,7 +282,7 @@ def dense_conv_dw(xin, dy, wshape, B, spatial, stride, lo, Out, cin, cout):
     real = [False] * (3 - nd) + [True] * nd
     kk = [k if r else 1 for r in real]
     ss = [stride if r else 1 for r in real]
-    return _dw_call(xin, xin.shape[1], dy, dy.shape[1], B, In, Out, kk, ss, lo, 0, cin, cout, wshape)
+    return _dw_call(xin, xin.shape[1], dy, dy.shape[1], B, In, Out, kk, ss, lo, 0, cin, cout, wshape, xf)
 
 
 class DenseConvTransposeFunction(torch.autograd.Function):

@@ -8,7 +8,9 @@ views).  Convolutions run on the dense implicit-GEMM kernels (csrc/urn_dense.hip
   * ConvTranspose k3 s2 p1 op1 (reference :164-172): one call per output parity class (only the valid taps each);
   * BatchNorm with batch statistics: the statistics come out of the producing convolution's epilogue (urn_dense_conv:
     stats), BatchNorm-apply + shortcut add (identity, or the shortcut conv's own BatchNorm) + ReLU are ONE row pass
-    (urn_dense_bn_act_fwd), their gradient two (reduce, apply: urn_dense_bn_act_bwd_*) -- BNActFunction below.  Channel
+    (urn_dense_bn_act_fwd), their gradient two (reduce, apply: urn_dense_bn_act_bwd_*) -- BNActFunction below; where
+    neither a ReLU nor a shortcut follows (residual1 -> residual2) the BatchNorm is folded into the next convolution's load
+    and never applied (BNFoldFunction, DeferredBN).  Channel
     counts those passes do not take (the num_class-wide output layer) use the sparse path's row kernels
     (urn_bn_relu_fwd/bwd).
 No index tables, no padded copies (the first GPU route ran every conv as a gather convolution over [27][n] int32 tables:
@@ -59,8 +61,17 @@ class DeferredBN(object):
     """raw output of a convolution whose BatchNorm has not been applied: handed to conv_bn_act(residual=...) so that the
     shortcut branch's BatchNorm, the add and the ReLU of a ResNetModule (reference uresnet_dense.py:72-82) are one pass"""
 
+    is_cuda = True
+
     def __init__(self, raw, stats, gamma, beta, eps, B, spatial):
         self.raw, self.stats, self.gamma, self.beta, self.eps, self.B, self.spatial = raw, stats, gamma, beta, eps, B, spatial
+
+    def size(self):
+        """shape of the tensor this stands for: (B, C, *spatial)"""
+        return torch.Size((self.B, self.raw.shape[1]) + tuple(self.spatial))
+
+    def dim(self):
+        return 2 + len(self.spatial)
 
 
 def _finalize(stats, n, c, eps, gamma, beta):
@@ -129,14 +140,58 @@ class BNActFunction(torch.autograd.Function):
         return (d_raw, o[0], o[1], None, None, None, d_res, o[4] if ctx.res_bn else None, o[5] if ctx.res_bn else None, None, None)
 
 
+class BNFoldFunction(torch.autograd.Function):
+    """The BatchNorm of a raw convolution output, NOT applied: returns (raw, scale, shift) for a consumer that folds
+    x * scale + shift into its load (urn_dense_conv / urn_dense_dw: xf).  The consumer's input gradient is the gradient
+    w.r.t. the BatchNorm OUTPUT; it arrives here as the gradient of the first result and is taken through the BatchNorm
+    (reduce + apply, urn_dense_bn_act_bwd_*) -- the gradients autograd would send to scale / shift are ignored, they are
+    that same dependence counted a second time."""
+
+    @staticmethod
+    def forward(ctx, raw, gamma, beta, stats, eps):
+        n, c = raw.shape
+        gamma = gamma.contiguous(); beta = beta.contiguous()
+        f = _finalize(stats, n, c, eps, gamma, beta)
+        ctx.save_for_backward(raw, gamma, f)
+        scale, shift = f[2].clone(), f[3].clone()
+        ctx.mark_non_differentiable(scale, shift)
+        return raw, scale, shift                    # the same rows: the consumer applies the affine map itself
+
+    @staticmethod
+    def backward(ctx, d_out, _ds, _dh):
+        raw, gamma, f = ctx.saved_tensors
+        L = _l.load()
+        n, c = raw.shape
+        d_out = d_out.contiguous()
+        slots = 64
+        sums = dc.zeros_f64((1, slots, 2, c), raw.device)
+        o = torch.empty((4, c), dtype=torch.float32, device=raw.device)
+        _l.check(L.urn_dense_bn_act_bwd_reduce(d_out.data_ptr(), None, raw.data_ptr(), f[0].data_ptr(), f[1].data_ptr(), None, None,
+                                               None, n, c, sums.data_ptr(), None, slots, _l.stream()), 'dense_bn_act_bwd_reduce')
+        _l.check(L.urn_dense_bn_bwd_finalize(sums.data_ptr(), 1, slots, n, c, o.data_ptr(), _l.stream()), 'dense_bn_bwd_finalize')
+        d_raw = torch.empty_like(raw)
+        _l.check(L.urn_dense_bn_act_bwd_apply(d_out.data_ptr(), None, raw.data_ptr(), gamma.data_ptr(), f[0].data_ptr(),
+                                              f[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), None, None, None, None, None, None,
+                                              d_raw.data_ptr(), None, n, c, _l.stream()), 'dense_bn_act_bwd_apply')
+        return d_raw, o[0], o[1], None, None
+
+
 def _conv_raw(x, w, b, stride, pad):
-    """convolution with the statistics of its output: (raw rows, stats slab or None, B, out_spatial)"""
-    rows, B, spatial = to_rows(x)
+    """convolution with the statistics of its output: (raw rows, stats slab or None, B, out_spatial).  x may be a
+    DeferredBN (the raw output of the previous convolution, its BatchNorm pending): the BatchNorm is folded into this
+    convolution's load and the normalised tensor is never written"""
+    xf = None
+    if isinstance(x, DeferredBN):
+        rows, scale, shift = BNFoldFunction.apply(x.raw, x.gamma, x.beta, x.stats, x.eps)
+        B, spatial = x.B, x.spatial
+        xf = (scale, shift)
+    else:
+        rows, B, spatial = to_rows(x)
     cout = w.shape[0]
     fused = dc.stats_ok(cout)
     stats = dc.new_stats(cout + (-cout) % 16, rows.device) if fused else None
     lo, hi = (int(pad[0]), int(pad[1])) if len(pad) else (0, 0)
-    y = dc.DenseConvFunction.apply(rows, w, b, B, tuple(spatial), stride, lo, hi, stats, False)
+    y = dc.DenseConvFunction.apply(rows, w, b, B, tuple(spatial), stride, lo, hi, stats, False, xf)
     k = w.shape[2]
     out_spatial = tuple((s + lo + hi - k) // stride + 1 for s in spatial)
     return y, stats, B, out_spatial

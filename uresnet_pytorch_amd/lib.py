@@ -121,10 +121,10 @@ SIGNATURES = {
                            c_void_p, c_void_p]),
     'urn_dense_conv_scratch_bytes': (c_i64, [c_int, c_int, c_void_p]),
     'urn_dense_conv': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_void_p,
-                               c_int, c_void_p, c_i64, c_void_p]),
+                               c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'urn_dense_dw_scratch_bytes': (c_i64, [c_int, c_void_p, c_void_p, c_int, c_int]),
     'urn_dense_dw': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_int, c_void_p]),
+                             c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     'urn_dense_fold': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'urn_dense_bn_act_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_int,
                                      c_void_p]),

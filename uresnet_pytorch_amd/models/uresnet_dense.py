@@ -56,7 +56,9 @@ class ResNetModule(nn.Module):
 
     def forward(self, input_tensor):
         shortcut = _conv_bn(self.shortcut, input_tensor, defer=True) if self.use_shortcut else input_tensor
-        residual = _conv_bn(self.residual1, input_tensor)          # no ReLU between the two (reference :78-81)
+        # no ReLU between the two (reference :78-81): on the GPU route residual1's BatchNorm stays pending and is folded into
+        # residual2's load (defer)
+        residual = _conv_bn(self.residual1, input_tensor, defer=True)
         return _conv_bn(self.residual2, residual, relu=True, residual=shortcut)   # relu(shortcut + residual)
 
 
