@@ -278,3 +278,34 @@ def test_dense_conv_with_folded_input_affine(dev, dim, spatial, cin, cout, k, st
         assert rel(wg.grad, wr.grad) < tol
     finally:
         dc.set_precision('fp32')
+
+
+def test_trainer_dense_graph_flag_matches_eager(dev):
+    """trainval with flags -graph (the dense step replayed from a captured HIP graph) against the eager trainer: same
+    initial weights, three train_step calls on changing batches -> same loss / accuracy, same parameters afterwards"""
+    from types import SimpleNamespace
+    from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+    from uresnet_pytorch_amd.trainval import trainval
+
+    def flags(graph):
+        return SimpleNamespace(MODEL_NAME='uresnet_dense', DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=2, SPATIAL_SIZE=16,
+                               NUM_CLASS=5, BN_MOMENTUM=0.9, TRAIN=True, GPUS=[0], LEARNING_RATE=1e-3, MODEL_PATH='', WEIGHT_PREFIX='',
+                               GRAPH=graph)
+    blobs = []
+    for s in range(3):
+        b = make_dense_blob([2 * s, 2 * s + 1], 16, 3)
+        blobs.append({'data': [[b['data'][0], b['data'][1]]], 'label': [[b['label'][0], b['label'][1]]]})
+    out = {}
+    for graph in (False, True):
+        torch.manual_seed(0)
+        t = trainval(flags(graph))
+        t.initialize()
+        res = [t.train_step(b, epoch=0., batch_size=2) for b in blobs]
+        out[graph] = (res, torch.cat([p.detach().flatten() for p in t._net.parameters()]).cpu())
+        assert (getattr(t, '_gstep', None) is not None) == graph
+    for re, rg in zip(out[False][0], out[True][0]):
+        assert abs(re['loss_seg'] - rg['loss_seg']) <= 1e-5 * abs(re['loss_seg'])
+        assert abs(re['accuracy'] - rg['accuracy']) <= 1e-6
+        assert len(rg['segmentation']) == 2 and rg['segmentation'][0].shape == re['segmentation'][0].shape
+        assert rel(torch.from_numpy(rg['segmentation'][1]), torch.from_numpy(re['segmentation'][1])) < 1e-5
+    assert rel(out[True][1], out[False][1]) < 1e-6

@@ -42,6 +42,7 @@ class URESNET_FLAGS:
     NUM_POINT = 2048
     PRECISION = 'fp32'
     LOSS_SCALE = 1.0
+    GRAPH = False
     NUM_CHANNEL = -1
     ITERATION = 10000
     REPORT_STEP = 100
@@ -97,6 +98,9 @@ class URESNET_FLAGS:
         a('-ls', '--loss_scale', type=float, default=self.LOSS_SCALE,
           help='loss scale of a training step (a power of two; gradients are unscaled before the optimizer): keeps the '
                'gradient operands of -prec fp16 inside its exponent range')
+        a('-graph', '--graph', action='store_true', default=self.GRAPH,
+          help='dense model on the GPU: replay the training step (forward + loss + backward) from a captured HIP graph '
+               '(one sub-step of fixed shape per iteration; anything else runs eagerly)')
         return parser
 
     def _build_parsers(self):

@@ -17,9 +17,13 @@ import torch
 
 
 class GraphedDenseStep(object):
-    def __init__(self, net, criterion, data, label, weight=None, warmup=3):
+    def __init__(self, net, criterion, data, label, weight=None, warmup=3, zero_grad=None, loss_scale=1.0):
+        """zero_grad: callable that clears the gradients IN PLACE (parallel.FlatGradients.zero: the parameters' .grad stay views
+        of the flat buffer, the backward pass accumulates into them); default: net.zero_grad(set_to_none=True).
+        loss_scale: the loss is multiplied by it before backward (flags -ls); the caller unscales the gradients."""
         assert data.is_cuda, 'graph capture needs GPU tensors'
         self.net, self.crit = net, criterion
+        self.zero_grad, self.loss_scale = zero_grad, float(loss_scale)
         self.data, self.label = data.clone(), label.clone()
         self.weight = None if weight is None else weight.clone()
         side = torch.cuda.Stream()
@@ -41,11 +45,14 @@ class GraphedDenseStep(object):
         self._keep = (_dc._POOL.buf, dict(_dc._SCRATCH))
 
     def _step(self):
-        self.net.zero_grad(set_to_none=True)
+        if self.zero_grad is not None:
+            self.zero_grad()
+        else:
+            self.net.zero_grad(set_to_none=True)
         out = self.net(self.data)
         w = None if self.weight is None else [self.weight[i] for i in range(self.weight.shape[0])]
         loss, acc = self.crit(out, self.data, self.label, w)
-        loss.backward()
+        (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
         acc_t = getattr(acc, '_t', None)              # utils.DeferredFloat: the accuracy tensor, still on the device
         return loss.detach(), acc_t, out.detach()
 

@@ -72,8 +72,42 @@ class trainval(object):
         self.tspent['save'] = time.time() - tstart
 
     # -- reference trainval.py:42-51
+    def _graph_step(self, data_blob, batch_size):
+        """flags -graph: the dense training step (forward + loss + backward) replayed from a captured HIP graph
+        (graphed.GraphedDenseStep: ~1,100 launches per step otherwise issued from Python).  Only for ONE sub-step of fixed
+        shape on one rank; returns None when the step does not qualify (the eager path then runs)."""
+        if not (getattr(self._flags, 'GRAPH', False) and self._flags.TRAIN and 'dense' in self._flags.MODEL_NAME
+                and self._device.type == 'cuda' and self._world == 1 and len(data_blob['data']) == 1
+                and data_blob.get('label') is not None):
+            return None
+        from .graphed import GraphedDenseStep
+        data = torch.stack([torch.as_tensor(d) for d in data_blob['data'][0]]).to(self._device)
+        label = torch.stack([torch.as_tensor(l) for l in data_blob['label'][0]]).to(self._device)
+        weight = data_blob.get('weight')
+        weight = None if weight is None else torch.stack([torch.as_tensor(w) for w in weight[0]]).to(self._device)
+        key = (tuple(data.shape), tuple(label.shape), None if weight is None else tuple(weight.shape))
+        scale = float(getattr(self._flags, 'LOSS_SCALE', 1.0) or 1.0)
+        if getattr(self, '_gstep_key', None) != key:
+            self._gstep = GraphedDenseStep(self._net, self._criterion, data, label, weight, zero_grad=self._grads.zero,
+                                           loss_scale=scale)
+            self._gstep_key = key
+        loss, acc = self._gstep(data, label, weight)
+        if scale != 1.0:
+            self._grads.flat.mul_(1.0 / scale)
+        self._optimizer.step()
+        self.last_slots = list(range(data.shape[0]))
+        out = self._gstep.out
+        return {'segmentation': [out[i].detach().clone() for i in range(out.shape[0])], 'accuracy': [acc.clone()],
+                'loss_seg': [loss.clone()]}
+
     def train_step(self, data_blob, epoch=None, batch_size=1):
         tstart = time.time()
+        res_combined = self._graph_step(data_blob, batch_size)
+        if res_combined is not None:
+            res_combined = self._finish(res_combined, batch_size)
+            self.tspent['train'] = time.time() - tstart
+            self.tspent_sum['train'] += self.tspent['train']
+            return res_combined
         self._loss = []
         # the host copies of logits/softmax/loss/accuracy (reference :126-131) are made AFTER the backward pass and
         # the optimizer step have been enqueued: same dict, no host stall between forward and backward (SURVEY 8f-2)
