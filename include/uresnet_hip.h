@@ -233,7 +233,7 @@ typedef struct {
      * pair-list kernel -- per tile of output rows and table row, the valid (input row, output row) pairs packed into
      * blocks of 16, so that the matrix pipe multiplies rules, not (16-row block, offset) products that are mostly
      * absent neighbours.  pairs == NULL with pairs_tile != 0 and K == 1 declares tbl the identity (a 1x1 convolution:
-     * scn.NetworkInNetwork).  pairs_tile == 0: the dense-table kernels.  fp32 operands only. */
+     * scn.NetworkInNetwork).  pairs_tile == 0: the dense-table kernels.  Reduced precision: see wt_frag_prec. */
     const int32_t *pairs;
     int pairs_tile;
     /* Optional, pair-list kernel only: the weights of `wt` once more in MFMA-fragment order,
@@ -242,9 +242,17 @@ typedef struct {
      * instead of 16 rows of 64 bytes (16 half-used lines): the kernel is bound by the cache lines a CU can address per
      * cycle, and the weight block is fetched again for nearly every block of 16 rules.  NULL: rows of wt. */
     const float *wt_frag;
+    /* Element type of wt_frag: 0 = fp32 (above), 1 = bf16, 2 = fp16 (urn_weight_fragments16: the same order with 16-bit
+     * elements, 512 bytes per 16 x 16 block -- a lane's 8 bytes ARE its A operand of v_mfma_f32_16x16x16_*).  The
+     * reduced-precision variants of the pair-list kernel run only on fragments of their own precision (they keep the
+     * weight blocks of an offset in half the registers and take two to four column blocks per wave); any other
+     * combination runs on the 2-D tile kernel. */
+    int wt_frag_prec;
 } urn_gconv_args;
 /* wt (K, cout, cin) -> fragment order (see urn_gconv_args.wt_frag); cin, cout multiples of 16 */
 int urn_weight_fragments(const float *wt, int K, int cout, int cin, float *wt_frag, void *stream);
+/* the same with elements rounded (RNE) to bf16 (precision 1) or fp16 (2): K * cout * cin 16-bit words */
+int urn_weight_fragments16(const float *wt, int K, int cout, int cin, int precision, void *wt_frag16, void *stream);
 int64_t urn_gconv_part_bytes(int64_t n_out, int cout);
 int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);
 /* weight gradient with the same input transform: x rows are used as relu(x*scale+shift) */

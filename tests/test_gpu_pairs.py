@@ -276,3 +276,56 @@ def test_pairs_fragment_ordered_weights_give_the_same_bits(dev, cin, cout):
         outs.append(y)
     L.urn_set_option(b'pairs_max_cin', 80)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('prec,tol', [(1, 6e-3), (2, 8e-4)])
+@pytest.mark.parametrize('cin,cout', [(16, 16), (32, 48), (64, 64), (96, 32), (128, 128), (224, 96)])
+def test_pairs_reduced_precision_on_16bit_fragments(dev, cin, cout, prec, tol):
+    """bf16 / fp16 operands on the pair lists (BASELINE configs[1] / configs[4] operand types): urn_weight_fragments16 +
+    urn_gconv_args.wt_frag_prec; one, two or four column blocks per wave by shape.  Against the fp64 product of the
+    unrounded operands within the operand type's bound (same bounds as the tile kernel's test in test_gpu_sparse.py),
+    and really on the pair-list kernel: with the lists withheld the call takes the 2-D tile kernel and differs in the last
+    bits (another summation order), with fp32 fragments it must fall back to it and give the tile kernel's bits."""
+    from uresnet_pytorch_amd import lib as _l, sparse_ops as so
+    L = _l.load()
+    S = 32
+    c, f = cloud(13, S, 2500, 2)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
+    n = geo.n[0]
+    g = torch.Generator(device='cpu').manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, generator=g).to(dev)
+    wt = (torch.randn(27, cout, cin, generator=g) * 0.1).to(dev)
+    wf16 = torch.empty(27 * cout * cin, dtype=torch.int16, device=dev)
+    _l.check(L.urn_weight_fragments16(wt.data_ptr(), 27, cout, cin, prec, wf16.data_ptr(), _l.stream()), 'weight_fragments16')
+    # the layout the header states, with 16-bit elements
+    o, cb, kb, q, r, i = 5, cout // 16 - 1, cin // 16 - 1, 2, 7, 3
+    got = wf16.view(torch.bfloat16 if prec == 1 else torch.float16)[((o * (cout // 16) + cb) * (cin // 16) + kb) * 256 + (q * 16 + r) * 4 + i]
+    assert float(got) == float(wt[o, 16 * cb + r, 16 * kb + 4 * q + i].to(got.dtype))
+    wf32 = torch.empty_like(wt)
+    _l.check(L.urn_weight_fragments(wt.data_ptr(), 27, cout, cin, wf32.data_ptr(), _l.stream()), 'weight_fragments')
+    pl = geo.pairs['nbr'][0]
+
+    def call(frag, frag_prec, with_lists):
+        y = torch.empty(n, cout, device=dev)
+        a = _l.GConvArgs()
+        a.x = x.data_ptr(); a.wt = wt.data_ptr(); a.tbl = geo.nbr[0].data_ptr(); a.ld = geo.ld; a.K = 27; a.flip = 0; a.n_out = n
+        a.cin = cin; a.cout = cout; a.y = y.data_ptr(); a.precision = prec + 1
+        if with_lists:
+            a.pairs = pl[0].data_ptr(); a.pairs_tile = pl[1]
+        a.wt_frag = None if frag is None else frag.data_ptr(); a.wt_frag_prec = frag_prec
+        _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
+        return y
+    y_pairs = call(wf16, prec, True)
+    y_tile = call(None, 0, False)
+    y_fallback = call(wf32, 0, True)
+    nbr = geo.nbr[0][:, :n].cpu().numpy()
+    xd, wd = x.double().cpu().numpy(), wt.double().cpu().numpy()
+    ref = np.zeros((n, cout))
+    for k in range(27):
+        m = nbr[k] >= 0
+        ref[m] += xd[nbr[k][m]] @ wd[k].T
+    e = rel(y_pairs.double().cpu().numpy(), ref)
+    assert 1e-6 < e < tol, e
+    assert rel(y_tile.double().cpu().numpy(), ref) < tol
+    assert torch.equal(y_fallback, y_tile)
+    assert not torch.equal(y_pairs, y_tile)

@@ -11,16 +11,20 @@ from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
 from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
 L = L_.load(); dev = torch.device('cuda:0')
 DEFAULTS = {'pairs_waves': 2560, 'pairs_wgs': 512, 'dw_blocks': 768, 'pairs_deep': 2, 'pairs_max_cin': 80, 'pairs_max_cout': 999,
-            'pairs_nc': 0, 'pairs_split': 0, 'pairs_split_kc1': 0, 'pairs_split_kc2': 0, 'pairs_split_kc3': 0, 'pairs_split_kc4': 0, 'pairs_split_kc5': 0, 'pairs_cbg': 0, 'dw_split': 2, 'dw_2stage': 0}
-flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=5, SPATIAL_SIZE=512, NUM_CLASS=5)
+            'pairs_nc': 0, 'pairs_split': 0, 'pairs_split_kc1': 0, 'pairs_split_kc2': 0, 'pairs_split_kc3': 0, 'pairs_split_kc4': 0, 'pairs_split_kc5': 0, 'pairs_cbg': 0, 'dw_split': 2, 'dw_2stage': 0, 'pairs_prec': 1, 'pairs_wgs16': 256}
+# CFG=5: BASELINE configs[4] shape (768^3, 200k voxels, uf 32, uns 7); PREC=fp32|bf16|fp16 (flags -prec)
+CFG5 = os.environ.get('CFG', '3') == '5'
+SS, NV, UF, UNS = (768, 200000, 32, 7) if CFG5 else (512, 50000, 16, 5)
+flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=UF, URESNET_NUM_STRIDES=UNS, SPATIAL_SIZE=SS, NUM_CLASS=5,
+                        PRECISION=os.environ.get('PREC', 'fp32'))
 torch.manual_seed(0)
 model = SparseUResNet(flags).to(dev).train(); crit = SparseSegmentationLoss(flags)
-blob = make_sparse_blob(list(range(int(os.environ.get('EVENTS', '1')))), 512, 50000)   # EVENTS=2: two events per GPU
+blob = make_sparse_blob(list(range(int(os.environ.get('EVENTS', '1')))), SS, NV)   # EVENTS=2: two events per GPU
 data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
 grads = parallel.FlatGradients(model); opt = parallel.FlatAdam(grads, lr=1e-3)
 def step():
     grads.zero(); out = model(data); loss, _ = crit(out, [data], [label], None); loss.backward(); grads.all_reduce(); opt.step()
-def run(n=20):
+def run(n=6 if CFG5 else 20):
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()

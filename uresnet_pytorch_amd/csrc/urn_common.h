@@ -64,4 +64,17 @@ __device__ __forceinline__ void urn_slab_sum2(const double *p, long ld, int slot
     }
     for (; k < slots; ++k) { v0 += p[(long)(2 * k) * ld]; v1 += p[(long)(2 * k + 1) * ld]; }
 }
+
+// four floats rounded (RNE) to bf16 (PREC 1) or fp16 (PREC 2), packed into 8 bytes: one lane's operand of v_mfma_f32_16x16x16_*
+template <int PREC>
+__device__ __forceinline__ uint2 urn_round16x4(f32x4 v)
+{
+    if constexpr (PREC == 1) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4));
+    } else {
+        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(uint2, __builtin_convertvector(v, h16x4));
+    }
+}
 #endif

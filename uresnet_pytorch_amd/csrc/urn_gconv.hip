@@ -678,6 +678,31 @@ extern "C" int urn_weight_fragments(const float *wt, int K, int cout, int cin, f
     return URN_OK;
 }
 
+// the same with 16-bit elements: thread = the 8 bytes of one lane
+template <int PREC>
+__global__ void k_weight_fragments16(const float *__restrict__ wt, long total4, int cout, int cin, uint2 *__restrict__ wf)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    const int lane = (int)(e & 63), r = lane & 15, q = lane >> 4;
+    long f = e >> 6;
+    const int kbn = cin / 16, cbn = cout / 16;
+    const int kb = (int)(f % kbn); f /= kbn;
+    const int cb = (int)(f % cbn); const long o = f / cbn;
+    wf[e] = urn_round16x4<PREC>(*(const f32x4 *)(wt + ((long)o * cout + 16 * cb + r) * cin + 16 * kb + 4 * q));
+}
+
+extern "C" int urn_weight_fragments16(const float *wt, int K, int cout, int cin, int precision, void *wt_frag16, void *stream)
+{
+    URN_CHECK_ARG(wt && wt_frag16 && K > 0 && cout > 0 && cin > 0 && cout % 16 == 0 && cin % 16 == 0, "channel counts must be multiples of 16");
+    URN_CHECK_ARG(precision == 1 || precision == 2, "precision: 1 bf16, 2 fp16");
+    const long total4 = (long)K * cout * cin / 4;
+    if (precision == 1) hipLaunchKernelGGL(k_weight_fragments16<1>, dim3(urn_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, wt, total4, cout, cin, (uint2 *)wt_frag16);
+    else hipLaunchKernelGGL(k_weight_fragments16<2>, dim3(urn_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, wt, total4, cout, cin, (uint2 *)wt_frag16);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
 extern "C" int urn_transpose_w(const float *w, int K, int a, int b, float *wt, void *stream)
 {
     URN_CHECK_ARG(w && wt && K > 0 && a > 0 && b > 0, "bad argument");

@@ -320,7 +320,7 @@ static const int g_opt_fin_in_kernel = 0;   // (the in-kernel finalize lived in 
 static int g_opt_pipe = 0;
 static int g_opt_kernel = 7;   // 7 = compacted rule lists when the call carries them (urn_gconv_pairs.hip), else the 2-D tile; 6 = 2-D workgroup tile (urn_gconv_tile.hip); 3 = register gather (fallback for shapes without a tile instantiation)
 extern int g_pairs_split_kc[9];
-extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs, g_dwp_waves, g_dwp_smax, g_dwp_dbg, g_dwp_cap;
+extern int g_pairs_waves, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs, g_pairs_wgs16, g_dwp_waves, g_dwp_smax, g_dwp_dbg, g_dwp_cap;
 // which calls that carry a pair list run on the pair-list kernel (measured per shape on the cfg3 geometry, tools/bench_pairs.py:
 // it wins for the strided pair and the narrow levels; the wide, small levels are faster on the LDS-staged 2-D tile kernel):
 // K == 8, or K == 27 with cin <= g_pairs_max_cin and cout <= g_pairs_max_cout; K == 1 only when g_pairs_nin is set
@@ -328,6 +328,7 @@ static int g_pairs_max_cin = 80, g_pairs_max_cout = 999, g_pairs_nin = 0;
 // with fragment-ordered weights (urn_gconv_args.wt_frag) the wide inputs win on the pair lists too (96 -> 48: 33 us against 43 on
 // the tile kernel and 42 without fragments; 128 -> 64: 40 against 41 and 49)
 static int g_pairs_frag_wide = 1;
+static int g_pairs_prec = 1;        // reduced-precision calls on the pair lists too (urn_set_option "pairs_prec"; 0: the 2-D tile kernel as before)
 static long g_opt_min_waves = 8192;
 
 extern "C" int urn_set_option(const char *key, int64_t value)
@@ -339,12 +340,14 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strncmp(key, "pairs_split_kc", 14) && key[14] >= '1' && key[14] <= '8' && !key[15]) { g_pairs_split_kc[key[14] - '0'] = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_waves")) { g_pairs_waves = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_frag_wide")) { g_pairs_frag_wide = value != 0; return URN_OK; }
+    if (!strcmp(key, "pairs_prec")) { g_pairs_prec = value != 0; return URN_OK; }
     if (!strcmp(key, "pairs_max_cin")) { g_pairs_max_cin = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_max_cout")) { g_pairs_max_cout = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_nin")) { g_pairs_nin = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_nc")) { g_pairs_nc = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_cbg")) { g_pairs_cbg = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_wgs")) { g_pairs_wgs = (int)value; return URN_OK; }
+    if (!strcmp(key, "pairs_wgs16")) { g_pairs_wgs16 = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_deep")) { g_pairs_deep = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_pairs")) { g_dw_pairs = value != 0; return URN_OK; }
     if (!strcmp(key, "net_wfrag")) { g_net_wfrag = value != 0; return URN_OK; }
@@ -476,7 +479,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     const Pick p = pick_tile(ks, u->cout / 16, u->n_out, split);
     GArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = u->x; a.wt = u->wt; a.wfrag = u->wt_frag; a.tbl = u->tbl; a.ld = (long)u->ld; a.K = u->K; a.flip = u->flip; a.n_cap = (long)u->n_out;
+    a.x = u->x; a.wt = u->wt; a.wfrag = u->wt_frag; a.wfrag_prec = u->wt_frag_prec; a.tbl = u->tbl; a.ld = (long)u->ld; a.K = u->K; a.flip = u->flip; a.n_cap = (long)u->n_out;
     a.cout = u->cout; a.cin = u->cin; a.res = u->res; a.y = u->y; a.xf_scale = u->xf_scale; a.xf_shift = u->xf_shift; a.epi = u->epilogue;
     a.part = u->part; a.e_x = u->e_x; a.e_scale = u->e_scale; a.e_shift = u->e_shift; a.e_mean = u->e_mean;
     a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg; a.stamps = g_opt_stamps;
@@ -525,7 +528,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     }
     // compacted rule lists: the call carries the list of its table (or asks for the identity list of a 1x1 convolution)
     const bool pairs_shape = u->K == 8 || (u->K == 1 && g_pairs_nin) || (u->K > 8 && (u->cin <= g_pairs_max_cin || (u->wt_frag && g_pairs_frag_wide)) && u->cout <= g_pairs_max_cout);
-    if (g_opt_kernel >= 7 && u->pairs_tile != 0 && a.prec == 0 && !in_kernel && pairs_shape && (u->pairs != nullptr || u->K == 1)) {
+    if (g_opt_kernel >= 7 && u->pairs_tile != 0 && (a.prec == 0 || g_pairs_prec) && !in_kernel && pairs_shape && (u->pairs != nullptr || u->K == 1)) {
         a.pairs = u->pairs; a.p_tile = u->pairs_tile;
         const int npp = urn_gconv_pairs_launch(a, u->n_out, st);
         if (npp > 0) {

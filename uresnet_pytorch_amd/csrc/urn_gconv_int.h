@@ -5,6 +5,7 @@
 struct GArgs {
     const float *x, *wt;
     const float *wfrag;   // optional (pair-list kernel): the same weights in MFMA-fragment order, see urn_gconv_args.wt_frag
+    int wfrag_prec;       // element type of wfrag: 0 fp32, 1 bf16, 2 fp16
     const int *tbl;
     long ld;
     int K, flip;

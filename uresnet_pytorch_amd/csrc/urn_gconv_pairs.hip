@@ -33,6 +33,12 @@ struct PairsDescs { int n; PairsDesc d[URN_PAIRS_MAX_TABLES]; };
 
 // KK = compile-time table height (27 / 8; 0 = generic): with it the K table words of a row are requested together and the
 // loop over the table rows is straight-line code (a load inside a rolled loop is a round trip per table row)
+// The file is compiled five times (Makefile: -DURN_PAIRS_PART=0..4) so that the build parallelises: part 0 holds the host
+// code and the fp32 kernels, parts 1 / 2 the bf16 kernels (one or two | four column blocks per wave), parts 3 / 4 the fp16 ones.
+#ifndef URN_PAIRS_PART
+#define URN_PAIRS_PART 0
+#endif
+#if URN_PAIRS_PART == 0
 template <int KK>
 __device__ __forceinline__ void pairs_build_tile(const PairsDesc &d, int *s_cnt)
 {
@@ -119,10 +125,35 @@ extern "C" int urn_pairs_build(int n_tables, const int32_t *const *tbl, const in
     return URN_OK;
 }
 
+#endif   // URN_PAIRS_PART == 0
+
+typedef short urn_s16x4 __attribute__((ext_vector_type(4)));
+template <int PREC>
+__device__ __forceinline__ urn_s16x4 pairs_cvt16(f32x4 v)
+{
+    return __builtin_bit_cast(urn_s16x4, urn_round16x4<PREC>(v));
+}
+// registers of one weight fragment: 16 bytes per lane in fp32, 8 with 16-bit fragments (urn_gconv_args.wt_frag_prec)
+template <int PREC> struct PairsW { typedef f32x4 type; };
+template <> struct PairsW<1> { typedef urn_s16x4 type; };
+template <> struct PairsW<2> { typedef urn_s16x4 type; };
+template <int PREC>
+__device__ __forceinline__ f32x4 pairs_mfma16(urn_s16x4 a, urn_s16x4 b, f32x4 c)
+{
+    if constexpr (PREC == 1) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    else {
+        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ convolution
 // KC: 16-channel groups per contraction chunk (cin = 16 * KC * nch); NC: 16-column blocks per wave; XF: rows are used as
 // relu(x * scale + shift) (folded BatchNorm+ReLU of the input)
-template <int KC, int NC, int XF, int DEEP>
+// PREC: MFMA operand precision, 0 fp32 (v_mfma_f32_16x16x4_f32), 1 bf16, 2 fp16 (v_mfma_f32_16x16x16_*: the 16 bytes a lane
+// gathers -- channels 4q..4q+3 of its pair -- rounded to 16 bits ARE its B operand, the weight fragment likewise its A
+// operand: one MFMA per 16-channel group instead of four; rows and weights stay fp32 in HBM, accumulation is fp32)
+template <int KC, int NC, int XF, int DEEP, int PREC = 0>
 __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && NC == 1 && DEEP == 0) ? 5 : 1) void k_gconv_pairs(GArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -226,7 +257,9 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
         pv = blk_p[(long)b * 16 + r];
         tv = (g.dbg & 512) ? 0 : blk_t[b];   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
     };
-    f32x4 a_cur[KC], a_nxt[KC], w_cur[KC][NC];
+    typedef typename PairsW<PREC>::type wfrag_t;
+    f32x4 a_cur[KC], a_nxt[KC];
+    wfrag_t w_cur[KC][NC];
     // (g.dbg 256: every pair gathers row 0 -- the loads stay, their cache lines collapse to one; 512: the weight block of offset 0
     //  for every block -- no reloads.  Timing only.)
     const int row_mask = (g.dbg & 256) ? 0 : 0xFFFFFF;
@@ -239,8 +272,17 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
     // (one contiguous kilobyte per 16 x 16 block: 8 cache lines; the rows of wt are 16 half-used lines per block, and the
     // kernel is bound by the lines a CU can address per cycle)
     const int kbn = cin / 16;
-    auto load_w = [&](f32x4 (&w)[KC][NC], int t, int ch) {
+    auto load_w = [&](wfrag_t (&w)[KC][NC], int t, int ch) {
         const int o = g.flip ? (K - 1 - t) : t;
+        if constexpr (PREC != 0) {
+            // 16-bit fragments (the launcher guarantees g.wfrag_prec == PREC): 8 bytes per lane, 512 per block
+            const urn_s16x4 *src = (const urn_s16x4 *)g.wfrag + (((long)o * (cout / 16) + col0 / 16) * kbn + ch * KC) * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int j = 0; j < KC; ++j) w[j][c] = src[((long)c * kbn + j) * 64];
+            return;
+        } else
         if (g.wfrag) {
             const float *src = g.wfrag + (((long)o * (cout / 16) + col0 / 16) * kbn + ch * KC) * 256 + lane * 4;
 #pragma unroll
@@ -249,11 +291,13 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
                 for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + ((long)c * kbn + j) * 256);
             return;
         }
-        const float *src = g.wt + ((long)o * cout + col0 + r) * cin + ch * (16 * KC) + 4 * q;
+        if constexpr (PREC == 0) {
+            const float *src = g.wt + ((long)o * cout + col0 + r) * cin + ch * (16 * KC) + 4 * q;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + (long)(16 * c) * cin + 16 * j);
+                for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + (long)(16 * c) * cin + 16 * j);
+        }
     };
 
     // (DEEP is a template parameter: the rotating sets cost registers in every instantiation that contains them)
@@ -292,15 +336,27 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
                 f32x4 acc[NC], acc2[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                if constexpr (PREC == 0) {
 #pragma unroll
-                for (int j = 0; j < KC; ++j)
+                    for (int j = 0; j < KC; ++j)
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
+                        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) {
+                                if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], use[j][tt], acc2[c]);
+                                else acc[c] = MFMA16(w_cur[j][c][tt], use[j][tt], acc[c]);
+                            }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const urn_s16x4 xa = pairs_cvt16<PREC>(use[j]);
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
-                            if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], use[j][tt], acc2[c]);
-                            else acc[c] = MFMA16(w_cur[j][c][tt], use[j][tt], acc[c]);
+                            if (j & 1) acc2[c] = pairs_mfma16<PREC>(w_cur[j][c], xa, acc2[c]);
+                            else acc[c] = pairs_mfma16<PREC>(w_cur[j][c], xa, acc[c]);
                         }
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = old[c] + (acc[c] + acc2[c]);
             };
@@ -362,15 +418,27 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
                 }
                 // D[column 4q+i of the block][pair r] = sum_k W[k][column] x[pair][k]: weights are the A operand.  Two
                 // accumulators alternate so that consecutive MFMAs are independent (40-cycle dependent latency vs 32 issue)
+                if constexpr (PREC == 0) {
 #pragma unroll
-                for (int j = 0; j < KC; ++j)
+                    for (int j = 0; j < KC; ++j)
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
+                        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) {
+                                if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc2[c]);
+                                else acc[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc[c]);
+                            }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const urn_s16x4 xa = pairs_cvt16<PREC>(a_cur[j]);
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
-                            if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc2[c]);
-                            else acc[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc[c]);
+                            if (j & 1) acc2[c] = pairs_mfma16<PREC>(w_cur[j][c], xa, acc2[c]);
+                            else acc[c] = pairs_mfma16<PREC>(w_cur[j][c], xa, acc[c]);
                         }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < KC; ++j) a_cur[j] = a_nxt[j];
             }
@@ -464,7 +532,51 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
     }
 }
 
+
+// ---- 16-bit variants, one translation unit per (precision, column blocks per wave) group
+bool urn_pairs16_p1(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);   // bf16, NC 1 | 2
+bool urn_pairs16_p2(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);   // bf16, NC 4
+bool urn_pairs16_p3(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);   // fp16, NC 1 | 2
+bool urn_pairs16_p4(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);   // fp16, NC 4
+#if URN_PAIRS_PART != 0
+template <int KC, int NC, int PREC>
+static void launch_pairs16(const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+{
+    const bool xf = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
+    if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 0, PREC>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 0, PREC>), grid, block, lds, st, a);
+}
+#define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs16<KCv, NCv, URN_P16_PREC>(a, grid, block, lds, st); return true; }
+#if URN_PAIRS_PART == 1 || URN_PAIRS_PART == 3
+#define URN_P16_PREC (URN_PAIRS_PART == 1 ? 1 : 2)
+#if URN_PAIRS_PART == 1
+bool urn_pairs16_p1(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+#else
+bool urn_pairs16_p3(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+#endif
+{
+    URN_PL(1, 1) URN_PL(2, 1) URN_PL(3, 1) URN_PL(4, 1) URN_PL(5, 1) URN_PL(6, 1) URN_PL(8, 1)
+    URN_PL(1, 2) URN_PL(2, 2) URN_PL(3, 2) URN_PL(4, 2) URN_PL(5, 2) URN_PL(6, 2) URN_PL(8, 2)
+    return false;
+}
+#else
+#define URN_P16_PREC (URN_PAIRS_PART == 2 ? 1 : 2)
+#if URN_PAIRS_PART == 2
+bool urn_pairs16_p2(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+#else
+bool urn_pairs16_p4(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+#endif
+{
+    URN_PL(1, 4) URN_PL(2, 4) URN_PL(3, 4) URN_PL(4, 4) URN_PL(5, 4) URN_PL(6, 4) URN_PL(8, 4)
+    return false;
+}
+#endif
+#undef URN_PL
+#endif   // URN_PAIRS_PART != 0
+
+#if URN_PAIRS_PART == 0
 int g_pairs_waves = 2560;    // a launch is split G ways until it has about this many waves (urn_set_option "pairs_waves"): alone more is faster (4096+), beside the weight gradients of the training step fewer are (A/B in one process, tools/ab_options.py: 3.21 ms per step at 4096, 3.12 at 3072, 3.06 at 2560, 3.09 at 2304, 3.12 at 2048, 3.19 at 1536)
+int g_pairs_wgs16 = 256;     // 16-bit operands: four column blocks per wave only while the launch keeps this many workgroups ("pairs_wgs16")
 int g_pairs_nc = 0;          // force the column blocks per wave (urn_set_option "pairs_nc"), 0 = automatic
 int g_pairs_split = 0;
 int g_pairs_split_kc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // force G for inputs of 16 KC channels (urn_set_option "pairs_split_kc<KC>"), 0 = automatic
@@ -493,6 +605,8 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
 {
     const int T = a.p_tile;
     if ((T != 32 && T != 64 && T != 128) || a.cin % 16 || a.cout % 16 || a.K > 27) return 0;
+    if (a.prec != 0 && (a.wfrag == nullptr || a.wfrag_prec != a.prec)) return 0;   // the 16-bit variants read 16-bit fragments only
+    if (a.prec == 0 && a.wfrag_prec != 0) a.wfrag = nullptr;                        // 16-bit fragments are of no use to the fp32 variants: rows of wt
     if (a.ldy % 4 || ((uintptr_t)a.y & 15) || (a.res && ((uintptr_t)a.res & 15)) || (a.e_x && ((uintptr_t)a.e_x & 15))) return 0;   // 16-byte epilogue accesses
     const int ks = a.cin / 16, nblk = a.cout / 16;
     int kc = 1;
@@ -503,7 +617,15 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     // enough waves; the weight fragments of an offset must stay in registers (KC * NC * 4 <= 48)
     int nc = 1;
     if (nblk % 2 == 0 && kc <= 4 && ntiles * (nblk / 2) >= 2 * g_pairs_wgs) nc = 2;
-    if (g_pairs_nc == 1 || (g_pairs_nc == 2 && nblk % 2 == 0 && kc <= 6)) nc = g_pairs_nc;
+    // 16-bit operands: one MFMA per 16-channel group, the launch is bound by its gathers -- two column blocks per wave
+    // wherever the fragments fit (768^3 / 200k voxels / uf 32 / uns 7 in fp16: 21.1 -> 19.0 ms per step)
+    // with 16-bit fragments (8 bytes per lane) the weight blocks of any chunk fit: four column blocks while the launch keeps
+    // g_pairs_wgs16 workgroups
+    if (a.prec != 0) {
+        nc = nblk % 2 == 0 ? 2 : 1;
+        if (nblk % 4 == 0 && ntiles * (nblk / 4) >= g_pairs_wgs16) nc = 4;
+    }
+    if (g_pairs_nc == 1 || (g_pairs_nc == 2 && nblk % 2 == 0 && (kc <= 6 || a.prec != 0)) || (g_pairs_nc == 4 && nblk % 4 == 0 && a.prec != 0)) nc = g_pairs_nc;
     const int cbg_all = nblk / nc;
     const int maxw = kc * (nc + 2) * 4 <= 64 ? 16 : 8;   // waves per workgroup (register budget, see __launch_bounds__)
     // Workgroups first: the deep levels have few tiles (103 of 64 rows at level 3 of cfg3), and one workgroup per tile left
@@ -515,7 +637,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
         if (cbg_all % d == 0 && (d == 1 || ntiles * (cbg_all / d) >= g_pairs_wgs)) { cbg = d; break; }
     if (g_pairs_cbg > 0 && cbg_all % g_pairs_cbg == 0 && g_pairs_cbg <= maxw) cbg = g_pairs_cbg;
     const int gy = cbg_all / cbg, cw = 16 * nc * cbg;
-    const bool deep = ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1 && kc <= 3 && a.pairs != nullptr;
+    const bool deep = a.prec == 0 && ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1 && kc <= 3 && a.pairs != nullptr;
     auto lds_bytes = [&](int G) {
         size_t w = (size_t)2 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
         return w * 4 + (size_t)2 * G * cw * 8 + (deep ? (size_t)cbg * G * URN_PAIRS_IDXB * 17 * 4 : 0);
@@ -529,8 +651,14 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
     const size_t lds = lds_bytes(G);
 #define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs2<KCv, NCv>(a, grid, block, lds, st); return (int)ntiles; }
+    if (a.prec != 0) {
+        const bool ok = nc == 4 ? (a.prec == 1 ? urn_pairs16_p2 : urn_pairs16_p4)(kc, nc, a, grid, block, lds, st)
+                                : (a.prec == 1 ? urn_pairs16_p1 : urn_pairs16_p3)(kc, nc, a, grid, block, lds, st);
+        return ok ? (int)ntiles : 0;
+    }
     URN_PL(1, 1) URN_PL(2, 1) URN_PL(3, 1) URN_PL(4, 1) URN_PL(5, 1) URN_PL(6, 1) URN_PL(8, 1)
     URN_PL(1, 2) URN_PL(2, 2) URN_PL(3, 2) URN_PL(4, 2) URN_PL(5, 2) URN_PL(6, 2)
 #undef URN_PL
     return 0;
 }
+#endif   // URN_PAIRS_PART == 0

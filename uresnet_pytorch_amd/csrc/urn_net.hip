@@ -180,6 +180,7 @@ struct urn_net {
     }
     float *wt_all = nullptr;             // transposed copy of every conv weight, same offsets as params
     float *wf_fwd = nullptr, *wf_bwd = nullptr;   // wt_all / params once more in MFMA-fragment order (urn_gconv_args.wt_frag)
+    int wf_prec = 0;                              // their element type (urn_gconv_args.wt_frag_prec): the operand precision in force when they were written
     float *ext_w = nullptr;              // urn_net_prepare_weights: the three copies live in the caller's buffer, already written
     bool w_prepared = false;
     hipEvent_t ev_w = nullptr;           // ... recorded behind them on the stream they were written on
@@ -242,7 +243,7 @@ struct urn_net {
     {
         urn_gconv_args a;
         memset(&a, 0, sizeof(a));
-        a.x = x; a.wt = wt; a.wt_frag = frag_of(wt, cin, cout); a.tbl = tbl; a.ld = geo.ld; a.K = K; a.flip = flip; a.n_out = n_out; a.cin = cin; a.cout = cout;
+        a.x = x; a.wt = wt; a.wt_frag = frag_of(wt, cin, cout); a.wt_frag_prec = wf_prec; a.tbl = tbl; a.ld = geo.ld; a.K = K; a.flip = flip; a.n_out = n_out; a.cin = cin; a.cout = cout;
         a.res = res; a.y = y;
         geo.pairs_of(tbl, a.pairs, a.pairs_tile);
         return urn_gconv_fwd_ex(&a, nullptr, st);
@@ -486,7 +487,7 @@ struct urn_net {
         if (!live()) return y;
         urn_gconv_args a;
         memset(&a, 0, sizeof(a));
-        a.x = in.x; a.wt = wt_all + c.w; a.wt_frag = frag_of(a.wt, c.cin, c.cout); a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
+        a.x = in.x; a.wt = wt_all + c.w; a.wt_frag = frag_of(a.wt, c.cin, c.cout); a.wt_frag_prec = wf_prec; a.tbl = tbl; a.ld = geo.ld; a.K = c.K; a.flip = 0; a.n_out = n_out;
         a.cin = c.cin; a.cout = c.cout; a.res = res; a.y = y.x;
         a.ldy = dst ? ld_dst : 0;
         geo.pairs_of(tbl, a.pairs, a.pairs_tile);
@@ -573,7 +574,7 @@ struct urn_net {
             dw_launch(c, &b, dy, tbl_f, n_out, ld_dy, scratch);
             urn_gconv_args a;
             memset(&a, 0, sizeof(a));
-            a.x = dy; a.wt = params + c.w; a.wt_frag = frag_of(a.wt, c.cout, c.cin); a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
+            a.x = dy; a.wt = params + c.w; a.wt_frag = frag_of(a.wt, c.cout, c.cin); a.wt_frag_prec = wf_prec; a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
             a.cin = c.cout; a.cout = c.cin; a.y = g; a.ldx = ld_dy;
             geo.pairs_of(tbl_b, a.pairs, a.pairs_tile);
             a.epilogue = 2; a.part = part;
@@ -811,6 +812,7 @@ struct TDescs { int n; TDesc d[URN_MAX_CONVS]; };
 // fragment-ordered copies (urn_gconv_args.wt_frag) of every conv weight with channel counts that are multiples of 16:
 // blockIdx.z = 0: of the transposed weights (forward operand), 1: of the parameters themselves (the input gradient's
 // operand: (K, cin, cout) read as (K, "cout" = cin, "cin" = cout)).  Thread = one 16-byte piece of the destination.
+template <int PREC>
 __global__ void k_fragments_all(TDescs t, const float *__restrict__ wt_all, const float *__restrict__ params,
                                 float *__restrict__ wf_fwd, float *__restrict__ wf_bwd)
 {
@@ -827,7 +829,10 @@ __global__ void k_fragments_all(TDescs t, const float *__restrict__ wt_all, cons
         long f = e >> 6;
         const int kb = (int)(f % kbn); f /= kbn;
         const int cb = (int)(f % cbn); const long o = f / cbn;
-        *(f32x4 *)(dst + e * 4) = *(const f32x4 *)(src + ((long)o * cout + 16 * cb + r) * cin + 16 * kb + 4 * q);
+        const f32x4 v = *(const f32x4 *)(src + ((long)o * cout + 16 * cb + r) * cin + 16 * kb + 4 * q);
+        // PREC != 0: 16-bit fragments (urn_gconv_args.wt_frag_prec) in the first half of the conv's region
+        if constexpr (PREC == 0) *(f32x4 *)(dst + e * 4) = v;
+        else ((uint2 *)dst)[e] = urn_round16x4<PREC>(v);
     }
 }
 
@@ -863,8 +868,10 @@ static void collect_all_convs(urn_net *net)
 }
 
 // launches that write the transposed and the fragment-ordered copies of every conv weight
+extern int g_opt_precision;   // urn_set_option("gconv_precision")
 static void launch_weight_copies(urn_net *net, const float *params, float *wt_all, float *wf_fwd, float *wf_bwd, hipStream_t st)
 {
+    net->wf_prec = g_opt_precision;
     for (size_t base = 0; base < net->convs.size(); base += URN_MAX_CONVS) {
         TDescs t;
         t.n = (int)std::min((size_t)URN_MAX_CONVS, net->convs.size() - base);
@@ -873,8 +880,11 @@ static void launch_weight_copies(urn_net *net, const float *params, float *wt_al
             t.d[i] = TDesc{c->K, c->cin, c->cout, (long)c->w};
         }
         hipLaunchKernelGGL(k_transpose_all, dim3(32, t.n), dim3(256), 0, st, t, params, wt_all);
-        if (wf_fwd)
-            hipLaunchKernelGGL(k_fragments_all, dim3(8, t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
+        if (wf_fwd) {
+            if (net->wf_prec == 1) hipLaunchKernelGGL(k_fragments_all<1>, dim3(8, t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
+            else if (net->wf_prec == 2) hipLaunchKernelGGL(k_fragments_all<2>, dim3(8, t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
+            else hipLaunchKernelGGL(k_fragments_all<0>, dim3(8, t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
+        }
     }
 }
 

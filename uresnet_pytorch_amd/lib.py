@@ -36,7 +36,7 @@ class GConvArgs(ctypes.Structure):
                 ('xs_invstd', ctypes.c_void_p), ('xs_scale', ctypes.c_void_p), ('xs_shift', ctypes.c_void_p),
                 ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p), ('precision', ctypes.c_int),
                 ('ldx', ctypes.c_int64), ('ldy', ctypes.c_int64), ('pairs', ctypes.c_void_p), ('pairs_tile', ctypes.c_int),
-                ('wt_frag', ctypes.c_void_p)]
+                ('wt_frag', ctypes.c_void_p), ('wt_frag_prec', ctypes.c_int)]
 
 
 class DenseGeom(ctypes.Structure):
@@ -81,6 +81,7 @@ SIGNATURES = {
     'urn_gconv_bwd_dw_pairs': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_i64,
                                        c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
     'urn_weight_fragments': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'urn_weight_fragments16': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'urn_transpose_w': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'urn_bn_scratch_bytes': (c_i64, [c_int]),
     'urn_bn_relu_fwd': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
@@ -212,4 +213,14 @@ def set_precision(name):
     """MFMA operand precision of the gather convolutions (forward, input gradient, weight gradient): the library
     default that calls without an explicit urn_gconv_args.precision use.  BASELINE configs[1] = 'bf16', configs[4] =
     'fp16'; tensors in HBM and the accumulation stay fp32."""
+    global _PRECISION
     load().urn_set_option(b'gconv_precision', PRECISIONS[name])
+    _PRECISION = PRECISIONS[name]
+
+
+_PRECISION = 0
+
+
+def precision():
+    """the library default set by set_precision: 0 fp32, 1 bf16, 2 fp16"""
+    return _PRECISION

@@ -258,8 +258,13 @@ def _gconv(x, wt, tbl, ld, K, flip, n_out, cin, cout, res=None, pairs=None):
         # the weights once more in MFMA-fragment order, as the executor hands them to the pair-list kernel (same kernel
         # choice and the same bits on both routes)
         wf = torch.empty_like(wt)
-        _l.check(L.urn_weight_fragments(_l.ptr(wt), K, cout, cin, wf.data_ptr(), _l.stream()), 'weight_fragments')
+        prec = _l.precision()
+        if prec:        # reduced precision: the pair-list kernel reads 16-bit fragments (urn_gconv_args.wt_frag_prec)
+            _l.check(L.urn_weight_fragments16(_l.ptr(wt), K, cout, cin, prec, wf.data_ptr(), _l.stream()), 'weight_fragments16')
+        else:
+            _l.check(L.urn_weight_fragments(_l.ptr(wt), K, cout, cin, wf.data_ptr(), _l.stream()), 'weight_fragments')
         a.wt_frag = wf.data_ptr()
+        a.wt_frag_prec = prec
     _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
     return y
 
