@@ -308,6 +308,7 @@ struct Pick { int mb, nb; };
 // tuning knobs (urn_set_option): software pipelining of the offset loop, and how many waves a launch must keep
 // before the column tile is widened
 int g_opt_precision = 0;   // default MFMA operand precision of the gather convolutions: 0 fp32, 1 bf16, 2 fp16
+extern int g_net_skip_dw;
 extern int g_dw_pairs;
 extern int g_pairs_deep;
 extern int g_dw_2stage;
@@ -350,6 +351,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "pairs_wgs16")) { g_pairs_wgs16 = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_deep")) { g_pairs_deep = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_pairs")) { g_dw_pairs = value != 0; return URN_OK; }
+    if (!strcmp(key, "net_dbg_skip_dw")) { g_net_skip_dw = value != 0; return URN_OK; }
     if (!strcmp(key, "net_wfrag")) { g_net_wfrag = value != 0; return URN_OK; }
     if (!strcmp(key, "dw_2stage")) { g_dw_2stage = value != 0; return URN_OK; }
     if (!strcmp(key, "dwp_cap")) { g_dwp_cap = value >= 1 && value <= 5 ? (int)value : 2; return URN_OK; }

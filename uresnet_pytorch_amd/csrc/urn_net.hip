@@ -20,6 +20,7 @@ int g_dw_group = 1;   // weight gradients per fork to the side stream (urn_set_o
 
 int g_net_wfrag = 1;       // fragment-ordered weight copies for the pair-list kernel (urn_set_option "net_wfrag")
 int g_dw_2stage = 0;       // weight gradients of the table kernel as per-chunk partial slabs + a fixed-order reduce instead of fp32 atomics (urn_set_option "dw_2stage")
+int g_net_skip_dw = 0;     // timing only (urn_set_option "net_dbg_skip_dw"): no weight-gradient launches -- what the step costs without them
 int g_dw_pairs = 0;        // weight gradients on the two-stage pair-list kernel (bitwise reproducible) instead of the atomics kernel (urn_set_option "dw_pairs")
 int g_net_side_probe = 4;   // candidate side streams tried by an executor's first backward (urn_set_option "net_side_probe"; 0/1 = keep the first)
 int g_net_side_verbose = 0;
@@ -270,6 +271,7 @@ struct urn_net {
                 void *scratch)
     {
         const int32_t *list; int tile;
+        if (g_net_skip_dw) return URN_OK;
         geo.pairs_of(tbl_f, list, tile);
         if (scratch && !g_dw_pairs) {
             if (!dw2_stream) dw2_stream = ws;
@@ -836,14 +838,33 @@ __global__ void k_fragments_all(TDescs t, const float *__restrict__ wt_all, cons
     }
 }
 
-__global__ void k_transpose_all(TDescs t, const float *__restrict__ params, float *__restrict__ wt)
+// wt[o][j][i] = w[o][i][j] for every conv: 32 x 32 tiles through LDS (both sides coalesced; the one-element-per-thread
+// form read with a stride of b floats: 428 us for the 30 M parameters of the 768^3 / uf 32 / uns 7 network, 240 MB of traffic)
+__global__ __launch_bounds__(256) void k_transpose_all(TDescs t, const float *__restrict__ params, float *__restrict__ wt)
 {
+    __shared__ float s_t[32][33];
     const TDesc d = t.d[blockIdx.y];
-    const long per = (long)d.a * d.b, total = per * d.K;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long o = e / per, rem = e - o * per;
-        const int j = (int)(rem / d.a), i = (int)(rem - (long)j * d.a);   // wt[o][j][i] = w[o][i][j]
-        wt[d.off + e] = params[d.off + o * per + (long)i * d.b + j];
+    const int ti_n = (d.a + 31) / 32, tj_n = (d.b + 31) / 32;
+    const long per = (long)d.a * d.b, ntiles = (long)d.K * ti_n * tj_n;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {     // workgroup-uniform
+        const long o = tile / (ti_n * tj_n);
+        const int rem = (int)(tile - o * (ti_n * tj_n));
+        const int i0 = (rem / tj_n) * 32, j0 = (rem % tj_n) * 32;
+        const float *src = params + d.off + o * per;
+        float *dst = wt + d.off + o * per;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + ty + 8 * k, j = j0 + tx;
+            if (i < d.a && j < d.b) s_t[ty + 8 * k][tx] = src[(long)i * d.b + j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + ty + 8 * k, i = i0 + tx;
+            if (i < d.a && j < d.b) dst[(long)j * d.a + i] = s_t[tx][ty + 8 * k];
+        }
+        __syncthreads();
     }
 }
 
@@ -879,11 +900,15 @@ static void launch_weight_copies(urn_net *net, const float *params, float *wt_al
             const ConvP *c = net->convs[base + i];
             t.d[i] = TDesc{c->K, c->cin, c->cout, (long)c->w};
         }
-        hipLaunchKernelGGL(k_transpose_all, dim3(32, t.n), dim3(256), 0, st, t, params, wt_all);
+        // workgroups per conv by the largest conv of the batch (the small ones leave at once): 32 for the cfg3 network, 512 for 224 -> 224
+        long big = 0;
+        for (int i = 0; i < t.n; ++i) big = std::max(big, (long)t.d[i].K * t.d[i].a * t.d[i].b);
+        const unsigned gx = (unsigned)std::min(512L, std::max(32L, big / 4096));
+        hipLaunchKernelGGL(k_transpose_all, dim3(gx, t.n), dim3(256), 0, st, t, params, wt_all);
         if (wf_fwd) {
-            if (net->wf_prec == 1) hipLaunchKernelGGL(k_fragments_all<1>, dim3(8, t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
-            else if (net->wf_prec == 2) hipLaunchKernelGGL(k_fragments_all<2>, dim3(8, t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
-            else hipLaunchKernelGGL(k_fragments_all<0>, dim3(8, t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
+            if (net->wf_prec == 1) hipLaunchKernelGGL(k_fragments_all<1>, dim3(std::max(8u, gx / 4), t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
+            else if (net->wf_prec == 2) hipLaunchKernelGGL(k_fragments_all<2>, dim3(std::max(8u, gx / 4), t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
+            else hipLaunchKernelGGL(k_fragments_all<0>, dim3(std::max(8u, gx / 4), t.n, 2), dim3(256), 0, st, t, (const float *)wt_all, params, wf_fwd, wf_bwd);
         }
     }
 }
