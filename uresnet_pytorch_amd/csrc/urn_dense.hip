@@ -412,17 +412,37 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
             // the 9 weight tiles of this z-slice: wt[(jz * 3 + jy) * 3 + jx][col_w0 + c][ch0 ..]; one flat loop
             {
                 const float *src = g.wt + ((long)(jz * 9) * g.cout + col_w0) * g.cin + ch0;
-                constexpr int TOTAL = 9 * NCOLS * PER;
-                for (int e = tid; e < TOTAL; e += 512) {
-                    const int tap = e / (NCOLS * PER), rem = e - tap * (NCOLS * PER);
-                    const int c = rem >> PER_LOG, k4 = rem & (PER - 1);
-                    const f32x4 v = *(const f32x4 *)(src + ((long)tap * g.cout + c) * g.cin + 4 * k4);
-                    if constexpr (PREC) {
-                        uint2 pk;
-                        pk.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); pk.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                        *(uint2 *)(s_w + tap * WTILE + c * ROWB + 8 * k4) = pk;
-                    } else {
-                        *(f32x4 *)(s_w + tap * WTILE + c * ROWB + 16 * k4) = v;
+                // (a plain loop waits for every load before it asks for the next: nine dependent round trips to HBM per slice
+                // at 32 x 64 -- the weights of a deep level are read exactly once; batches of WB loads per thread instead)
+                constexpr int TOTAL = 9 * NCOLS * PER, NITW = (TOTAL + 511) / 512, WB = NITW > 5 ? 5 : NITW;
+#pragma unroll
+                for (int h0 = 0; h0 < NITW; h0 += WB) {
+                    f32x4 wv[WB];
+#pragma unroll
+                    for (int it = 0; it < WB; ++it) {
+                        const int e = (h0 + it) * 512 + tid;
+                        wv[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (h0 + it < NITW && e < TOTAL) {
+                            const int tap = e / (NCOLS * PER), rem = e - tap * (NCOLS * PER);
+                            const int c = rem >> PER_LOG, k4 = rem & (PER - 1);
+                            wv[it] = *(const f32x4 *)(src + ((long)tap * g.cout + c) * g.cin + 4 * k4);
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < WB; ++it) {
+                        const int e = (h0 + it) * 512 + tid;
+                        if (h0 + it < NITW && e < TOTAL) {
+                            const int tap = e / (NCOLS * PER), rem = e - tap * (NCOLS * PER);
+                            const int c = rem >> PER_LOG, k4 = rem & (PER - 1);
+                            const f32x4 v = wv[it];
+                            if constexpr (PREC) {
+                                uint2 pk;
+                                pk.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); pk.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                                *(uint2 *)(s_w + tap * WTILE + c * ROWB + 8 * k4) = pk;
+                            } else {
+                                *(f32x4 *)(s_w + tap * WTILE + c * ROWB + 16 * k4) = v;
+                            }
+                        }
                     }
                 }
             }
