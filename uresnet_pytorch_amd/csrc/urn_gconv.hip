@@ -373,13 +373,14 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
                         const float bv = s_b[buf][4 * ks + q][ni_[sl] * 16 + m];
                         acc[sl] = MFMA16(av, bv, acc[sl]);
                     } else {
+                        // lane (m, q): pairs 16 ks + 4 q + i (i < 4) of channel m of the block = one transposing read of the
+                        // pair-major tile (ds_read_b64_tr_b16; four ds_read_u16 per operand made the 16-bit kernel
+                        // LDS-instruction bound: 8 reads per MFMA)
                         typedef short s16x4 __attribute__((ext_vector_type(4)));
-                        s16x4 av, bv;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {   // lane (m, q): pairs 16 ks + 4 q + i of channel m of the block
-                            av[i] = (short)((const unsigned short *)&s_a[buf][16 * ks + 4 * q + i][0])[mi_[sl] * 16 + m];
-                            bv[i] = (short)((const unsigned short *)&s_b[buf][16 * ks + 4 * q + i][0])[ni_[sl] * 16 + m];
-                        }
+                        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                        const int tr_row = 16 * ks + 4 * q + (m >> 2), tr_col = 4 * (m & 3);
+                        const s16x4 av = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)((unsigned short *)&s_a[buf][tr_row][0] + mi_[sl] * 16 + tr_col));
+                        const s16x4 bv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)((unsigned short *)&s_b[buf][tr_row][0] + ni_[sl] * 16 + tr_col));
                         if constexpr (PREC == 1) {
                             acc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc[sl], 0, 0, 0);
                         } else {
