@@ -914,16 +914,18 @@ __global__ __launch_bounds__(512) void k_dense_dw(DenseDwArgs g)
                 const int rz = rb / g.TY, ry = rb % g.TY;
                 const int bv0 = ((g.s[0] * rz + dz) * g.box[1] + (g.s[1] * ry + dy_)) * g.box[2] + dx;   // + s * voxel
                 if constexpr (PREC) {
+                    // lane (r, q) wants voxels 4q..4q+3 of channel r: one transposing read per operand (lane addresses voxel
+                    // 4q + (r >> 2), channels 4 (r & 3)..+3; see k_dense_dw3) instead of four ds_read_u16
+                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
                     s16x4 af[2], bf[2];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int vx = 4 * q + j;
+                    {
+                        const int vx = 4 * q + (r >> 2), cc = 4 * (r & 3);
                         const unsigned char *xr = s_box + (long)(bv0 + g.s[2] * vx) * rowb;
                         const unsigned char *dr = s_dy + (long)(rb * 16 + vx) * rowb;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            af[i][j] = *(const short *)(xr + 2 * (16 * i + r));
-                            bf[i][j] = *(const short *)(dr + 2 * (16 * i + r));
+                            af[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(xr + 2 * (16 * i + cc)));
+                            bf[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(dr + 2 * (16 * i + cc)));
                         }
                     }
 #pragma unroll
