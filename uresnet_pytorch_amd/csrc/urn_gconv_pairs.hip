@@ -153,8 +153,10 @@ __device__ __forceinline__ f32x4 pairs_mfma16(urn_s16x4 a, urn_s16x4 b, f32x4 c)
 // PREC: MFMA operand precision, 0 fp32 (v_mfma_f32_16x16x4_f32), 1 bf16, 2 fp16 (v_mfma_f32_16x16x16_*: the 16 bytes a lane
 // gathers -- channels 4q..4q+3 of its pair -- rounded to 16 bits ARE its B operand, the weight fragment likewise its A
 // operand: one MFMA per 16-channel group instead of four; rows and weights stay fp32 in HBM, accumulation is fp32)
+// (register estimate of the loop: rows as loaded + operand registers 8 KC, weight fragments 4 KC NC)
+#define URN_PAIRS_REGS(KC, NC, PREC) ((KC) * ((NC) + 2) * 4)
 template <int KC, int NC, int XF, int DEEP, int PREC = 0>
-__global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && NC == 1 && DEEP == 0) ? 5 : 1) void k_gconv_pairs(GArgs g)
+__global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (KC <= 2 && NC == 1 && DEEP == 0) ? 5 : 1) void k_gconv_pairs(GArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // diagnostics, compiled only with -DURN_PAIRS_STAMP (make CXXFLAGS+=...): s_memtime at the phase boundaries of every wave
@@ -247,26 +249,63 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
     // the MFMA's A operand and the gathered rows as its B operand, lane (r, q) ends up with output columns 4q..4q+3 of
     // pair r: one 16-byte read-modify-write of the slab per column block.  Within one block the pairs have distinct
     // tile rows, so the plain (non-atomic) update is race-free; padding pairs all hit the trash row, which nobody reads.
-    auto load_idx = [&](int b, int &pv, int &tv) {
+    // GATHER MAPPING.  The MFMA wants lane (r, q) to hold channels 4q..4q+3 of pair r -- but a wave-load in that shape costs the
+    // CU ~66 cycles whatever the cache level (tools/ubench/gather_map.hip): the texture addresser takes the lanes four at a time,
+    // and four consecutive lanes are four different rows = four lines.  Loaded row-major instead -- lane l reads piece l & 3 of
+    // pair l >> 2, a quad of lanes = 64 contiguous bytes -- the same 16 rows x 64 bytes cost 22 cycles; the fragment shape is
+    // then restored across the lanes (ds_bpermute_b32: lane (r, q) takes the registers of lane 4 r + q).
+    const int gp = lane >> 2, gq = lane & 3;               // gather pair / 16-byte piece of this lane
+    const int bp_addr = 4 * (4 * r + q);                   // byte address of the source lane for ds_bpermute
+    auto load_idx = [&](int b, int &pv, int &tv, int &pl) {
         if (ident) {
-            const int lr = 16 * b + r;
+            const int lr = 16 * b + r, lg = 16 * b + gp;
             pv = lr < rows_here ? (((int)row0 + lr) | (lr << 24)) : (T << 24);
+            pl = lg < rows_here ? (int)row0 + lg : 0;
             tv = 0;
             return;
         }
         pv = blk_p[(long)b * 16 + r];
+        pl = blk_p[(long)b * 16 + gp];
         tv = (g.dbg & 512) ? 0 : blk_t[b];   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
     };
     typedef typename PairsW<PREC>::type wfrag_t;
-    f32x4 a_cur[KC], a_nxt[KC];
+    f32x4 a_nxt[KC];                 // rows as loaded (row-major lane mapping)
+    wfrag_t a_cur[KC];               // the MFMA's B operand: folded BatchNorm applied, rounded (PREC != 0), in fragment shape
     wfrag_t w_cur[KC][NC];
     // (g.dbg 256: every pair gathers row 0 -- the loads stay, their cache lines collapse to one; 512: the weight block of offset 0
     //  for every block -- no reloads.  Timing only.)
     const int row_mask = (g.dbg & 256) ? 0 : 0xFFFFFF;
-    auto load_a = [&](f32x4 (&a)[KC], int pv, int ch) {
-        const float *src = g.x + (long)(pv & row_mask) * g.ldx + ch * (16 * KC) + 4 * q;
+    auto load_a = [&](f32x4 (&a)[KC], int pl, int ch) {
+        const float *src = g.x + (long)(pl & row_mask) * g.ldx + ch * (16 * KC) + 4 * gq;
 #pragma unroll
         for (int j = 0; j < KC; ++j) a[j] = *(const f32x4 *)(src + 16 * j);
+    };
+    // loaded rows of channel chunk ch -> operand registers: relu(x * scale + shift) where the input BatchNorm is folded (this
+    // lane holds channels 4 gq..+3 of the group), rounding, then the transpose across the lanes
+    auto ready = [&](const f32x4 (&raw)[KC], wfrag_t (&dst)[KC], int ch) {
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            f32x4 v = raw[j];
+            if constexpr (XF != 0) {
+                const f32x4 sc = *(const f32x4 *)(s_xf + ch * (16 * KC) + 16 * j + 4 * gq);
+                const f32x4 sh = *(const f32x4 *)(s_xf + cin + ch * (16 * KC) + 16 * j + 4 * gq);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
+            }
+            if constexpr (PREC == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float f = v[k];   // (__builtin_bit_cast applied to a vector ELEMENT takes element 0 with this hipcc)
+                    dst[j][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(f)));
+                }
+            } else {
+                const uint2 h = urn_round16x4<PREC>(v);
+                uint2 t;
+                t.x = (unsigned)__builtin_amdgcn_ds_bpermute(bp_addr, (int)h.x);
+                t.y = (unsigned)__builtin_amdgcn_ds_bpermute(bp_addr, (int)h.y);
+                dst[j] = __builtin_bit_cast(urn_s16x4, t);
+            }
+        }
     };
     // weight block of offset t, columns of this wave, channel chunk ch: from the fragment-ordered copy when the call has one
     // (one contiguous kilobyte per 16 x 16 block: 8 cache lines; the rows of wt are 16 half-used lines per block, and the
@@ -315,24 +354,17 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
             int *my_idx = (int *)(s_p + 2 * (long)G * cw) + (long)wave * (URN_PAIRS_IDXB * 17);
             int w_key = -1;
             // one block: slab rows of pair word pv / offset tv from `use`; the rows of the block two ahead go into `ld`
-            auto step = [&](f32x4 (&use)[KC], f32x4 (&ld)[KC], int pv, int tv, int pv_ld) {
+            auto step = [&](f32x4 (&use)[KC], f32x4 (&ld)[KC], int pv, int tv, int pl_ld) {
                 const int t_c = __builtin_amdgcn_readfirstlane(tv);
                 float *dptr = slab + (long)((unsigned)pv >> 24) * LDW + 4 * q;
                 f32x4 old[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) old[c] = *(const f32x4 *)(dptr + 16 * c);
                 if (t_c != w_key) { load_w(w_cur, t_c, 0); w_key = t_c; }   // wave-uniform; before the younger row loads
-                load_a(ld, pv_ld, 0);
+                load_a(ld, pl_ld, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (XF != 0) {
-#pragma unroll
-                    for (int j = 0; j < KC; ++j) {
-                        const f32x4 sc = *(const f32x4 *)(s_xf + 16 * j + 4 * q);
-                        const f32x4 sh = *(const f32x4 *)(s_xf + cin + 16 * j + 4 * q);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) use[j][k] = fmaxf(fmaf(use[j][k], sc[k], sh[k]), 0.f);
-                    }
-                }
+                wfrag_t opn[KC];
+                ready(use, opn, 0);
                 f32x4 acc[NC], acc2[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -343,19 +375,17 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
                         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                             for (int c = 0; c < NC; ++c) {
-                                if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], use[j][tt], acc2[c]);
-                                else acc[c] = MFMA16(w_cur[j][c][tt], use[j][tt], acc[c]);
+                                if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], opn[j][tt], acc2[c]);
+                                else acc[c] = MFMA16(w_cur[j][c][tt], opn[j][tt], acc[c]);
                             }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < KC; ++j) {
-                        const urn_s16x4 xa = pairs_cvt16<PREC>(use[j]);
+                    for (int j = 0; j < KC; ++j)
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
-                            if (j & 1) acc2[c] = pairs_mfma16<PREC>(w_cur[j][c], xa, acc2[c]);
-                            else acc[c] = pairs_mfma16<PREC>(w_cur[j][c], xa, acc[c]);
+                            if (j & 1) acc2[c] = pairs_mfma16<PREC>(w_cur[j][c], opn[j], acc2[c]);
+                            else acc[c] = pairs_mfma16<PREC>(w_cur[j][c], opn[j], acc[c]);
                         }
-                    }
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = old[c] + (acc[c] + acc2[c]);
@@ -365,13 +395,14 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
                 for (int i = lane; i < nbk * 16; i += 64) my_idx[i] = blk_p[(long)c0 * 16 + i];
                 for (int i = lane; i < nbk; i += 64) my_idx[URN_PAIRS_IDXB * 16 + i] = blk_t[c0 + i];
                 auto PV = [&](int b) { return my_idx[((b < c1 ? b : c1 - 1) - c0) * 16 + r]; };
+                auto PL = [&](int b) { return my_idx[((b < c1 ? b : c1 - 1) - c0) * 16 + gp]; };   // the lane's gather pair
                 auto TV = [&](int b) { return my_idx[URN_PAIRS_IDXB * 16 + (b - c0)]; };
-                load_a(A0, PV(c0), 0);
-                load_a(A1, PV(c0 + 1), 0);
+                load_a(A0, PL(c0), 0);
+                load_a(A1, PL(c0 + 1), 0);
                 for (int b = c0; b < c1; b += 3) {
-                    step(A0, A2, PV(b), TV(b), PV(b + 2));
-                    if (b + 1 < c1) step(A1, A0, PV(b + 1), TV(b + 1), PV(b + 3));
-                    if (b + 2 < c1) step(A2, A1, PV(b + 2), TV(b + 2), PV(b + 4));
+                    step(A0, A2, PV(b), TV(b), PL(b + 2));
+                    if (b + 1 < c1) step(A1, A0, PV(b + 1), TV(b + 1), PL(b + 3));
+                    if (b + 2 < c1) step(A2, A1, PV(b + 2), TV(b + 2), PL(b + 4));
                 }
             }
         }
@@ -382,16 +413,17 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
     // change; when it does they are requested BEFORE the next step's rows, so that waiting for them (s_waitcnt vmcnt(N)
     // counts in issue order) leaves the younger row loads in flight.
     if (b0 < b1) {
-        int pv_c, tv_c, pv_n, tv_n, pv_nn, tv_nn;
-        load_idx(b0, pv_c, tv_c);
-        load_idx(b0 + 1 < b1 ? b0 + 1 : b1 - 1, pv_n, tv_n);
-        load_idx(b0 + 2 < b1 ? b0 + 2 : b1 - 1, pv_nn, tv_nn);
+        int pv_c, tv_c, pv_n, tv_n, pv_nn, tv_nn, pl_c, pl_n, pl_nn;
+        load_idx(b0, pv_c, tv_c, pl_c);
+        load_idx(b0 + 1 < b1 ? b0 + 1 : b1 - 1, pv_n, tv_n, pl_n);
+        load_idx(b0 + 2 < b1 ? b0 + 2 : b1 - 1, pv_nn, tv_nn, pl_nn);
         int t_c = __builtin_amdgcn_readfirstlane(tv_c);
-        load_a(a_cur, pv_c, 0);
+        load_a(a_nxt, pl_c, 0);
+        ready(a_nxt, a_cur, 0);
         int w_key = -1;
         for (int b = b0; b < b1; ++b) {
-            int pv_n3, tv_n3;
-            load_idx(b + 3 < b1 ? b + 3 : b1 - 1, pv_n3, tv_n3);
+            int pv_n3, tv_n3, pl_n3;
+            load_idx(b + 3 < b1 ? b + 3 : b1 - 1, pv_n3, tv_n3, pl_n3);
             const int t_n = __builtin_amdgcn_readfirstlane(tv_n);
             // old slab values of this block's rows: requested now, needed after the MFMAs
             float *dptr = slab + (long)((unsigned)pv_c >> 24) * LDW + 4 * q;
@@ -405,17 +437,8 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
                 const bool last = ch + 1 == nch;
                 const int key = t_c * nch + ch;
                 if (key != w_key) { load_w(w_cur, t_c, ch); w_key = key; }   // wave-uniform
-                load_a(a_nxt, last ? pv_n : pv_c, last ? 0 : ch + 1);
+                load_a(a_nxt, last ? pl_n : pl_c, last ? 0 : ch + 1);
                 __builtin_amdgcn_sched_barrier(0);   // keep the requests in front of the MFMAs (the scheduler sinks them otherwise)
-                if constexpr (XF != 0) {
-#pragma unroll
-                    for (int j = 0; j < KC; ++j) {
-                        const f32x4 sc = *(const f32x4 *)(s_xf + ch * (16 * KC) + 16 * j + 4 * q);
-                        const f32x4 sh = *(const f32x4 *)(s_xf + cin + ch * (16 * KC) + 16 * j + 4 * q);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) a_cur[j][k] = fmaxf(fmaf(a_cur[j][k], sc[k], sh[k]), 0.f);
-                    }
-                }
                 // D[column 4q+i of the block][pair r] = sum_k W[k][column] x[pair][k]: weights are the A operand.  Two
                 // accumulators alternate so that consecutive MFMAs are independent (40-cycle dependent latency vs 32 issue)
                 if constexpr (PREC == 0) {
@@ -430,21 +453,22 @@ __global__ __launch_bounds__(KC * (NC + 2) * 4 <= 64 ? 1024 : 512, (KC <= 2 && N
                             }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < KC; ++j) {
-                        const urn_s16x4 xa = pairs_cvt16<PREC>(a_cur[j]);
+                    for (int j = 0; j < KC; ++j)
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
-                            if (j & 1) acc2[c] = pairs_mfma16<PREC>(w_cur[j][c], xa, acc2[c]);
-                            else acc[c] = pairs_mfma16<PREC>(w_cur[j][c], xa, acc[c]);
+                            if (j & 1) acc2[c] = pairs_mfma16<PREC>(w_cur[j][c], a_cur[j], acc2[c]);
+                            else acc[c] = pairs_mfma16<PREC>(w_cur[j][c], a_cur[j], acc[c]);
                         }
-                    }
                 }
-#pragma unroll
-                for (int j = 0; j < KC; ++j) a_cur[j] = a_nxt[j];
+                // the next step's rows (they have had the MFMAs to arrive): fold, round, transpose into the operand registers
+                // (the weight block one step ahead as well, unconditionally into a second register set, was measured: 2.74 ->
+                // 2.81 ms per cfg3 step, 12.4 -> 13.2 at the cfg5 shape in fp16 -- the extra requests cost more than the wait)
+                ready(a_nxt, a_cur, last ? 0 : ch + 1);
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = old[c] + (acc[c] + acc2[c]);
             pv_c = pv_n; pv_n = pv_nn; pv_nn = pv_n3;
+            pl_c = pl_n; pl_n = pl_nn; pl_nn = pl_n3;
             t_c = t_n; tv_n = tv_nn; tv_nn = tv_n3;
         }
     }
@@ -627,7 +651,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     }
     if (g_pairs_nc == 1 || (g_pairs_nc == 2 && nblk % 2 == 0 && (kc <= 6 || a.prec != 0)) || (g_pairs_nc == 4 && nblk % 4 == 0 && a.prec != 0)) nc = g_pairs_nc;
     const int cbg_all = nblk / nc;
-    const int maxw = kc * (nc + 2) * 4 <= 64 ? 16 : 8;   // waves per workgroup (register budget, see __launch_bounds__)
+    const int maxw = URN_PAIRS_REGS(kc, nc, a.prec) <= 64 ? 16 : 8;   // waves per workgroup (register budget, see __launch_bounds__)
     // Workgroups first: the deep levels have few tiles (103 of 64 rows at level 3 of cfg3), and one workgroup per tile left
     // most of the 256 CUs idle (measured 56 -> 15 us at level 4, 80 -> 80, with one column group per workgroup): give a
     // workgroup fewer column groups (its rows are then gathered by several workgroups -- L2 hits) until the launch has
