@@ -530,7 +530,7 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     }
     // compacted rule lists: the call carries the list of its table (or asks for the identity list of a 1x1 convolution)
     const bool pairs_shape = u->K == 8 || (u->K == 1 && g_pairs_nin) || (u->K > 8 && (u->cin <= g_pairs_max_cin || (u->wt_frag && g_pairs_frag_wide)) && u->cout <= g_pairs_max_cout);
-    if (g_opt_kernel >= 7 && u->pairs_tile != 0 && (a.prec == 0 || g_pairs_prec) && !in_kernel && pairs_shape && (u->pairs != nullptr || u->K == 1)) {
+    if (g_opt_kernel >= 7 && off32_ok && u->pairs_tile != 0 && (a.prec == 0 || g_pairs_prec) && !in_kernel && pairs_shape && (u->pairs != nullptr || u->K == 1)) {
         a.pairs = u->pairs; a.p_tile = u->pairs_tile;
         const int npp = urn_gconv_pairs_launch(a, u->n_out, st);
         if (npp > 0) {

@@ -202,10 +202,22 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     const int *blk_t = hdr + URN_PAIRS_HDR;
     const int *blk_p = blk_t + urn_pairs_tpad(K, T);
     const int nblk = ident ? (rows_here + 15) >> 4 : hdr[0];
-    const int b0 = nblk * gi / G;
+    // ADDRESSING of the block loop.  With 64-bit pointers every gathered row cost two v_mad_u64_u32, a v_lshl_add_u64 and moves,
+    // every pair word and weight block the same again: ~130 vector instructions per block of 8 MFMAs at 32 -> 32, the loop was
+    // bound by VALU issue (quarter-rate 64-bit multiplies), not by its loads.  Buffer loads instead: one descriptor per operand
+    // array, the wave-uniform part of an address in the scalar offset (block number, offset, chunk: SALU), the lane's part a
+    // 32-bit VGPR -- one v_mad_u32_u24 per gathered row, nothing per pair word or weight block.  (Anything derived from
+    // threadIdx is divergent to the compiler, also the wave number: made scalar with readfirstlane once.)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)g.x, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)g.pairs, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)g.wfrag, 0, -1, 0x00020000);
+    const int pw_t = (int)((long)tile * urn_pairs_words(K, T)) + URN_PAIRS_HDR;   // word index of blk_t[0] / blk_p[0] in g.pairs
+    const int pw_p = pw_t + (int)urn_pairs_tpad(K, T);
+    const int ldxb = (int)g.ldx * 4;
+    const int b0 = __builtin_amdgcn_readfirstlane(nblk * gi / G);
     // (g.dbg: timing-only ablations of whole phases, tools/bench_pairs.py abl: 32 = no block loop, 64 = return before the epilogue,
     //  128 = one block per wave)
-    const int b1 = (g.dbg & 32) ? b0 : ((g.dbg & 128) ? min(b0 + 1, nblk * (gi + 1) / G) : nblk * (gi + 1) / G);   // nblk <= 27 * 8, G <= 16
+    const int b1 = __builtin_amdgcn_readfirstlane((g.dbg & 32) ? b0 : ((g.dbg & 128) ? min(b0 + 1, nblk * (gi + 1) / G) : nblk * (gi + 1) / G));   // nblk <= 27 * 8, G <= 16
 
     if constexpr (XF != 0) {
         if (g.xs_sums[0] != nullptr) {
@@ -264,9 +276,10 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
             tv = 0;
             return;
         }
-        pv = blk_p[(long)b * 16 + r];
-        pl = blk_p[(long)b * 16 + gp];
-        tv = (g.dbg & 512) ? 0 : blk_t[b];   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
+        const int so = (pw_p + b * 16) * 4;   // scalar (b is)
+        pv = __builtin_amdgcn_raw_buffer_load_b32(rs_p, r * 4, so, 0);
+        pl = __builtin_amdgcn_raw_buffer_load_b32(rs_p, gp * 4, so, 0);
+        tv = (g.dbg & 512) ? 0 : (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, 0, (pw_t + b) * 4, 0);   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
     };
     typedef typename PairsW<PREC>::type wfrag_t;
     f32x4 a_nxt[KC];                 // rows as loaded (row-major lane mapping)
@@ -276,9 +289,11 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     //  for every block -- no reloads.  Timing only.)
     const int row_mask = (g.dbg & 256) ? 0 : 0xFFFFFF;
     auto load_a = [&](f32x4 (&a)[KC], int pl, int ch) {
-        const float *src = g.x + (long)(pl & row_mask) * g.ldx + ch * (16 * KC) + 4 * gq;
+        const int vo = (int)__umul24((unsigned)(pl & row_mask), (unsigned)ldxb) + 16 * gq;
+        const int so = ch * (64 * KC);
 #pragma unroll
-        for (int j = 0; j < KC; ++j) a[j] = *(const f32x4 *)(src + 16 * j);
+        for (int j = 0; j < KC; ++j)
+            a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo + 64 * j, so, 0));
     };
     // loaded rows of channel chunk ch -> operand registers: relu(x * scale + shift) where the input BatchNorm is folded (this
     // lane holds channels 4 gq..+3 of the group), rounding, then the transpose across the lanes
@@ -311,23 +326,26 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     // (one contiguous kilobyte per 16 x 16 block: 8 cache lines; the rows of wt are 16 half-used lines per block, and the
     // kernel is bound by the lines a CU can address per cycle)
     const int kbn = cin / 16;
+    const int cb0 = __builtin_amdgcn_readfirstlane(col0 / 16);   // first column block of the wave
     auto load_w = [&](wfrag_t (&w)[KC][NC], int t, int ch) {
         const int o = g.flip ? (K - 1 - t) : t;
         if constexpr (PREC != 0) {
             // 16-bit fragments (the launcher guarantees g.wfrag_prec == PREC): 8 bytes per lane, 512 per block
-            const urn_s16x4 *src = (const urn_s16x4 *)g.wfrag + (((long)o * (cout / 16) + col0 / 16) * kbn + ch * KC) * 64 + lane;
+            const int so = ((o * (cout / 16) + cb0) * kbn + ch * KC) * 512;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int j = 0; j < KC; ++j) w[j][c] = src[((long)c * kbn + j) * 64];
+                for (int j = 0; j < KC; ++j)
+                    w[j][c] = __builtin_bit_cast(urn_s16x4, __builtin_amdgcn_raw_buffer_load_b64(rs_w, lane * 8, so + (c * kbn + j) * 512, 0));
             return;
         } else
         if (g.wfrag) {
-            const float *src = g.wfrag + (((long)o * (cout / 16) + col0 / 16) * kbn + ch * KC) * 256 + lane * 4;
+            const int so = ((o * (cout / 16) + cb0) * kbn + ch * KC) * 1024;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + ((long)c * kbn + j) * 256);
+                for (int j = 0; j < KC; ++j)
+                    w[j][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, so + (c * kbn + j) * 1024, 0));
             return;
         }
         if constexpr (PREC == 0) {
@@ -637,6 +655,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     for (int d : {8, 6, 5, 4, 3, 2})
         if (ks % d == 0) { kc = d; break; }
     const long ntiles = (n_out + T - 1) / T;
+    if ((double)ntiles * (double)urn_pairs_words(a.K, T) * 4.0 >= 2147483648.0) return 0;   // 32-bit offsets into the lists (rows / weights: the dispatcher's off32_ok)
     // two column blocks per wave halve the gathers (every wave of a tile gathers the same rows) when the launch still has
     // enough waves; the weight fragments of an offset must stay in registers (KC * NC * 4 <= 48)
     int nc = 1;
