@@ -619,6 +619,7 @@ bool urn_pairs16_p4(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_
 #if URN_PAIRS_PART == 0
 int g_pairs_waves = 2560;    // a launch is split G ways until it has about this many waves (urn_set_option "pairs_waves"): alone more is faster (4096+), beside the weight gradients of the training step fewer are (A/B in one process, tools/ab_options.py: 3.21 ms per step at 4096, 3.12 at 3072, 3.06 at 2560, 3.09 at 2304, 3.12 at 2048, 3.19 at 1536)
 int g_pairs_wgs16 = 256;     // 16-bit operands: four column blocks per wave only while the launch keeps this many workgroups ("pairs_wgs16")
+int g_pairs_waves_fwd = 0;   // the same for launches that do not run beside the weight gradients (forward: epilogue != 2), 0 = g_pairs_waves ("pairs_waves_fwd")
 int g_pairs_nc = 0;          // force the column blocks per wave (urn_set_option "pairs_nc"), 0 = automatic
 int g_pairs_split = 0;
 int g_pairs_split_kc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // force G for inputs of 16 KC channels (urn_set_option "pairs_split_kc<KC>"), 0 = automatic
@@ -686,7 +687,8 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
         return w * 4 + (size_t)2 * G * cw * 8 + (deep ? (size_t)cbg * G * URN_PAIRS_IDXB * 17 * 4 : 0);
     };
     int G = 1;
-    while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < g_pairs_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= 65536) ++G;
+    const int want_waves = (a.epi != 2 && g_pairs_waves_fwd > 0) ? g_pairs_waves_fwd : g_pairs_waves;
+    while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < want_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= 65536) ++G;
     if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= 65536) G = g_pairs_split;
     if (kc <= 8 && g_pairs_split_kc[kc] > 0 && cbg * g_pairs_split_kc[kc] <= maxw && lds_bytes(g_pairs_split_kc[kc]) <= 65536) G = g_pairs_split_kc[kc];
     if (lds_bytes(G) > 65536) return 0;
