@@ -424,8 +424,8 @@ class HeadFunction(torch.autograd.Function):
         nc = weight.shape[0]
         dl = dl.contiguous()
         dx = torch.empty_like(rows)
-        dW = torch.zeros_like(weight)
-        db = torch.zeros(nc, dtype=torch.float32, device=rows.device)
+        acc = torch.zeros(nc * m + nc, dtype=torch.float32, device=rows.device)   # the kernel accumulates: one fill for both
+        dW = acc[:nc * m].view(nc, m); db = acc[nc * m:]
         _l.check(L.urn_head_bwd(dl.data_ptr(), rows.data_ptr(), None, n, m, nc, weight.data_ptr(), dx.data_ptr(),
                                 dW.data_ptr(), db.data_ptr(), _l.stream()), 'head_bwd')
         return dx, dW, (db if ctx.has_bias else None)
