@@ -182,7 +182,7 @@ def main():
         if os.path.exists(tpath):
             traffic = round(json.load(open(tpath)).get('gconv_traffic_bytes_per_launch', 0.0)) or None
         roofline = {
-            'bound': 'mfma', 'kernel': 'k_gconv_pairs<KC,NC,XF> (compacted rule lists) / k_gconv_tile<KS,RB,CB> by shape: all gather-conv forward + input-gradient launches',
+            'bound': 'mfma', 'kernel': 'k_gconv_pairs<KC,NC,XF,DEEP,PREC> (compacted rule lists) / k_gconv_tile<KS,RB,CB> by shape: all gather-conv forward + input-gradient launches',
             'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic,
             'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json)',
