@@ -219,6 +219,36 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
     //  128 = one block per wave)
     const int b1 = __builtin_amdgcn_readfirstlane((g.dbg & 32) ? b0 : ((g.dbg & 128) ? min(b0 + 1, nblk * (gi + 1) / G) : nblk * (gi + 1) / G));   // nblk <= 27 * 8, G <= 16
 
+    // GATHER MAPPING.  The MFMA wants lane (r, q) to hold channels 4q..4q+3 of pair r -- but a wave-load in that shape costs the
+    // CU ~66 cycles whatever the cache level (tools/ubench/gather_map.hip): the texture addresser takes the lanes four at a time,
+    // and four consecutive lanes are four different rows = four lines.  Loaded row-major instead -- lane l reads piece l & 3 of
+    // pair l >> 2, a quad of lanes = 64 contiguous bytes -- the same 16 rows x 64 bytes cost 22 cycles; the fragment shape is
+    // then restored across the lanes (ds_bpermute_b32: lane (r, q) takes the registers of lane 4 r + q).
+    const int gp = lane >> 2, gq = lane & 3;               // gather pair / 16-byte piece of this lane
+    const int bp_addr = 4 * (4 * r + q);                   // byte address of the source lane for ds_bpermute
+    auto load_idx = [&](int b, int &pv, int &tv, int &pl) {
+        if (ident) {
+            const int lr = 16 * b + r, lg = 16 * b + gp;
+            pv = lr < rows_here ? (((int)row0 + lr) | (lr << 24)) : (T << 24);
+            pl = lg < rows_here ? (int)row0 + lg : 0;
+            tv = 0;
+            return;
+        }
+        const int so = (pw_p + b * 16) * 4;   // scalar (b is)
+        pv = __builtin_amdgcn_raw_buffer_load_b32(rs_p, r * 4, so, 0);
+        pl = __builtin_amdgcn_raw_buffer_load_b32(rs_p, gp * 4, so, 0);
+        tv = (g.dbg & 512) ? 0 : (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, 0, (pw_t + b) * 4, 0);   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
+    };
+    // the first pair words of the wave's share are requested BEFORE the statistics of the folded BatchNorm are fetched and
+    // finalized below: two round trips side by side instead of one after the other at the head of every folding launch
+    int pv_c = 0, tv_c = 0, pv_n = 0, tv_n = 0, pv_nn = 0, tv_nn = 0, pl_c = 0, pl_n = 0, pl_nn = 0;
+    if constexpr (DEEP == 0) {
+        if (b0 < b1) {
+            load_idx(b0, pv_c, tv_c, pl_c);
+            load_idx(b0 + 1 < b1 ? b0 + 1 : b1 - 1, pv_n, tv_n, pl_n);
+            load_idx(b0 + 2 < b1 ? b0 + 2 : b1 - 1, pv_nn, tv_nn, pl_nn);
+        }
+    }
     if constexpr (XF != 0) {
         if (g.xs_sums[0] != nullptr) {
             // statistics of the input rows accumulated by the producers: same arithmetic as k_bn_finalize_fwd_f
@@ -261,26 +291,6 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
     // the MFMA's A operand and the gathered rows as its B operand, lane (r, q) ends up with output columns 4q..4q+3 of
     // pair r: one 16-byte read-modify-write of the slab per column block.  Within one block the pairs have distinct
     // tile rows, so the plain (non-atomic) update is race-free; padding pairs all hit the trash row, which nobody reads.
-    // GATHER MAPPING.  The MFMA wants lane (r, q) to hold channels 4q..4q+3 of pair r -- but a wave-load in that shape costs the
-    // CU ~66 cycles whatever the cache level (tools/ubench/gather_map.hip): the texture addresser takes the lanes four at a time,
-    // and four consecutive lanes are four different rows = four lines.  Loaded row-major instead -- lane l reads piece l & 3 of
-    // pair l >> 2, a quad of lanes = 64 contiguous bytes -- the same 16 rows x 64 bytes cost 22 cycles; the fragment shape is
-    // then restored across the lanes (ds_bpermute_b32: lane (r, q) takes the registers of lane 4 r + q).
-    const int gp = lane >> 2, gq = lane & 3;               // gather pair / 16-byte piece of this lane
-    const int bp_addr = 4 * (4 * r + q);                   // byte address of the source lane for ds_bpermute
-    auto load_idx = [&](int b, int &pv, int &tv, int &pl) {
-        if (ident) {
-            const int lr = 16 * b + r, lg = 16 * b + gp;
-            pv = lr < rows_here ? (((int)row0 + lr) | (lr << 24)) : (T << 24);
-            pl = lg < rows_here ? (int)row0 + lg : 0;
-            tv = 0;
-            return;
-        }
-        const int so = (pw_p + b * 16) * 4;   // scalar (b is)
-        pv = __builtin_amdgcn_raw_buffer_load_b32(rs_p, r * 4, so, 0);
-        pl = __builtin_amdgcn_raw_buffer_load_b32(rs_p, gp * 4, so, 0);
-        tv = (g.dbg & 512) ? 0 : (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, 0, (pw_t + b) * 4, 0);   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
-    };
     typedef typename PairsW<PREC>::type wfrag_t;
     f32x4 a_nxt[KC];                 // rows as loaded (row-major lane mapping)
     wfrag_t a_cur[KC];               // the MFMA's B operand: folded BatchNorm applied, rounded (PREC != 0), in fragment shape
@@ -432,10 +442,6 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
     // change; when it does they are requested BEFORE the next step's rows, so that waiting for them (s_waitcnt vmcnt(N)
     // counts in issue order) leaves the younger row loads in flight.
     if (b0 < b1) {
-        int pv_c, tv_c, pv_n, tv_n, pv_nn, tv_nn, pl_c, pl_n, pl_nn;
-        load_idx(b0, pv_c, tv_c, pl_c);
-        load_idx(b0 + 1 < b1 ? b0 + 1 : b1 - 1, pv_n, tv_n, pl_n);
-        load_idx(b0 + 2 < b1 ? b0 + 2 : b1 - 1, pv_nn, tv_nn, pl_nn);
         int t_c = __builtin_amdgcn_readfirstlane(tv_c);
         load_a(a_nxt, pl_c, 0);
         ready(a_nxt, a_cur, 0);
