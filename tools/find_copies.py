@@ -30,3 +30,15 @@ for e in prof.events():
 for (name, where), c in sorted(cnt.items(), key=lambda kv: -kv[1]):
     print('%5.1f per step  %-16s %s' % (c / N, name, where))
 
+
+# device-side memcpy / memset / tiny blit launches and the CPU op that issued them
+cnt2 = collections.Counter()
+for e in prof.events():
+    ks = getattr(e, 'kernels', None) or []
+    for k in ks:
+        if 'emcpy' in k.name or 'emset' in k.name or 'copyBuffer' in k.name or 'fillBuffer' in k.name:
+            st = [x for x in (e.stack or []) if 'uresnet_pytorch_amd' in x or 'find_copies' in x or 'bench' in x]
+            cnt2[(k.name[:40], e.name, st[0] if st else ' | '.join((e.stack or ['?'])[:2]), str(e.input_shapes)[:60])] += 1
+print('--- device copies by issuing op')
+for k, c in sorted(cnt2.items(), key=lambda kv: -kv[1]):
+    print('%5.1f per step  %s' % (c / N, ' || '.join(k)))
