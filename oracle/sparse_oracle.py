@@ -276,6 +276,8 @@ class SparseUResNetOracle:
             ymask = y
         if getattr(self, 'keep_acts', False):
             self.acts[prefix] = y
+            # the pre-activation as well: tests bound |pre| at every entry whose ReLU branch differs from the GPU's
+            self.pre[prefix] = bn_relu_fwd(x, g, b, False)[0]
 
         def back(dy):
             dx, dg, db = bn_relu_bwd(x, ymask, dy, g, mean, invstd, True)
@@ -345,6 +347,7 @@ class SparseUResNetOracle:
         self.geo = geo = Geometry(coords, feats, self.spatial, self.L, mode=3)
         self.G = {}
         self.acts = {}
+        self.pre = {}
         x, b_stem = self._conv('sparseModel.1.weight', geo.feats, geo.nbr[0], geo.nbr_inv[0])
         x, b_u = self._U('sparseModel.2', 0, x)
         x, b_bn = self._bn('sparseModel.3', x)

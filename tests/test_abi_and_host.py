@@ -197,3 +197,110 @@ def test_deferred_float_behaves_like_a_float():
     assert float(np.array([d, DeferredFloat(torch.tensor(0.25))]).sum()) == 1.0        # trainval sums per-entry accuracies
     assert '%.2f' % d == '0.75' and '{:f}'.format(d) == '0.750000' and 0.0 <= d <= 1.0 and d > 0.5 and bool(d)
     assert d._t is None                                                                 # the device tensor is released after use
+
+
+def _cli_flags(argv):
+    from uresnet_pytorch_amd.flags import URESNET_FLAGS
+    return URESNET_FLAGS().parse_args(argv, run=False)
+
+
+def test_checkpoint_module_prefix_flag_roundtrip(tmp_path):
+    """-cmp / --ckpt_module_prefix (reference trainval.py:37,152-154,181): the reference saves the state of a
+    DataParallel-wrapped module, every key 'module.<name>', and restores with strict=False -- a file without the prefix
+    would restore NOTHING there, silently.  With the flag every key carries the prefix; the file loads into a
+    'module.'-wrapped model (strict=False, no missing and no unexpected keys) and back through initialize()."""
+    from uresnet_pytorch_amd.trainval import trainval
+    from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+    base = ['train', '-mn', 'uresnet_dense', '-io', 'synthetic_dense', '-dd', '2', '-uf', '4', '-uns', '2', '-ss', '16', '-nc', '3',
+            '-bs', '2', '-mbs', '2', '-wp', str(tmp_path / 'snap'), '-sd', '1']
+    with pytest.raises(SystemExit):
+        _cli_flags(base + ['-ls', 'x'])
+    with pytest.raises(ValueError):
+        _cli_flags(base + ['-ls', '3'])                   # not a power of two
+    assert _cli_flags(base).CKPT_MODULE_PREFIX is False
+    flags = _cli_flags(base + ['-cmp', '-ls', '4096'])
+    assert flags.CKPT_MODULE_PREFIX is True and flags.LOSS_SCALE == 4096.0
+    flags.GPUS = []                                        # CPU
+    t = trainval(flags)
+    t.initialize()
+    b = make_dense_blob([0, 1], 16, 2, 3)
+    t.train_step({'data': [[b['data'][0], b['data'][1]]], 'label': [[b['label'][0], b['label'][1]]]}, epoch=0., batch_size=2)
+    t.save_state(9)
+    ck = torch.load(str(tmp_path / 'snap-9.ckpt'), weights_only=True)
+    assert set(ck.keys()) == {'global_step', 'state_dict', 'optimizer'} and ck['global_step'] == 9
+    assert all(k.startswith('module.') for k in ck['state_dict']) and len(ck['state_dict']) == len(t._net.state_dict())
+
+    class Wrapped(torch.nn.Module):                        # what the reference's GraphDataParallel(net) looks like to load_state_dict
+        def __init__(self, m):
+            super().__init__(); self.module = m
+    from uresnet_pytorch_amd.models import DenseUResNet
+    w = Wrapped(DenseUResNet(flags))
+    missing, unexpected = w.load_state_dict(ck['state_dict'], strict=False)
+    assert not missing and not unexpected
+    for (k1, v1), (k2, v2) in zip(t._net.state_dict().items(), w.module.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    flags2 = _cli_flags(base + ['-mp', str(tmp_path / 'snap-9.ckpt')]); flags2.GPUS = []
+    t2 = trainval(flags2)
+    assert t2.initialize() == 10
+    for (k1, v1), (k2, v2) in zip(t._net.state_dict().items(), t2._net.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_npz_readers_serve_the_blob_contract(tmp_path):
+    """-io npz_sparse / npz_dense behind io_factory (reference iotools.py:5-10, iotools_sparse.py:120-160,
+    311-318, iotools_dense.py:195-198): per-GPU (N, d+2) rows with the step-wide batch id, (N, 1) labels, class-balancing
+    weights with -cw, wrap-around at the end of the file, store_segment -> output file; the trainer steps on the blob."""
+    from uresnet_pytorch_amd.iotools import io_factory
+    from uresnet_pytorch_amd.iotools import array_io
+    from uresnet_pytorch_amd.iotools.synthetic import generate_event, make_dense_blob
+    events = []
+    for seed in range(5):
+        c, v, l = generate_event(seed, 32, 100 + 10 * seed)
+        events.append({'voxels': c, 'feature': v, 'label': l})
+    path = str(tmp_path / 'ev.npz')
+    array_io.write_sparse_npz(path, events)
+    argv = ['train', '-mn', 'uresnet_sparse', '-io', 'npz_sparse', '-if', path, '-dkeys', 'data,label', '-cw', '-ss', '32', '-nc', '5',
+            '-bs', '4', '-mbs', '2', '--gpus', '0,1', '-sh', '0', '-of', str(tmp_path / 'out.npz')]
+    flags = _cli_flags(argv)
+    assert flags.DATA_KEYS == ['data', 'label', '_weights_']
+    io = io_factory(flags)
+    io.initialize()
+    assert io.num_entries() == 5 and io.num_channels() == 1 and io.batch_per_step() == 4
+    idx, blob = io.next()
+    assert [i.tolist() for i in idx] == [[0, 1], [2, 3]]
+    for g in range(2):
+        d, lab, w = blob['data'][g], blob['label'][g], blob['_weights_'][g]
+        n = sum(len(events[e]['voxels']) for e in idx[g])
+        assert d.shape == (n, 5) and d.dtype == np.float32 and lab.shape == (n, 1) and w.shape == (n, 1)
+        assert sorted(np.unique(d[:, 3]).tolist()) == [2.0 * g, 2.0 * g + 1]      # batch id = position in the step
+        e0 = events[idx[g][0]]
+        k = len(e0['voxels'])
+        assert np.array_equal(d[:k, :3], e0['voxels'].astype(np.float32)) and np.array_equal(d[:k, 4], e0['feature'])
+        assert np.array_equal(lab[:k, 0], e0['label'].astype(np.float32))
+        assert np.allclose(w[:k], array_io.class_weights(lab[:k]))
+        cls, cnt = np.unique(lab[:k], return_counts=True)
+        if cls.tolist() == list(range(len(cls))):                                  # labels 0..k-1 present: plain class balancing
+            assert np.allclose(w[:k][lab[:k] == cls[0]], k / (len(cls) * cnt[0]))
+    idx2, _ = io.next()
+    assert [i.tolist() for i in idx2] == [[4, 0], [1, 2]]                          # wraps around
+    soft = [np.random.default_rng(0).dirichlet(np.ones(5), size=len(blob['data'][g])).astype(np.float32) for g in range(2)]
+    io.store_segment(idx, blob['data'], soft)
+    io.finalize()
+    out = np.load(str(tmp_path / 'out.npz'))
+    assert sorted(out.files) == sorted(['prediction/%d' % i for i in range(4)] + ['softmax/%d' % i for i in range(4)])
+    assert out['prediction/1'].shape == (len(events[1]['voxels']),)
+    # dense reader + one trainer step on its blob (CPU)
+    b = make_dense_blob([0, 1, 2], 16, 2, 3)
+    dpath = str(tmp_path / 'dense.npz')
+    array_io.write_dense_npz(dpath, {'data': b['data'], 'label': b['label']})
+    fl = _cli_flags(['train', '-mn', 'uresnet_dense', '-io', 'npz_dense', '-if', dpath, '-dkeys', 'data,label', '-dd', '2', '-uf', '4',
+                     '-uns', '2', '-ss', '16', '-nc', '3', '-bs', '2', '-mbs', '2', '-sh', '0', '-it', '2', '-rs', '1'])
+    fl.GPUS = []
+    from uresnet_pytorch_amd import main_funcs
+    fl.TRAIN = True
+    h = main_funcs.prepare(fl)
+    assert h.data_io.num_entries() == 3 and h.data_io.num_channels() == 1
+    main_funcs.train_loop(fl, h)
+    assert h.iteration == 2
+    with pytest.raises(NotImplementedError):
+        io_factory(SimpleNamespace(IO_TYPE='larcv_sparse', GPUS=[], BATCH_SIZE=1, MINIBATCH_SIZE=1))

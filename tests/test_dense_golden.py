@@ -32,6 +32,75 @@ def load(name, device='cpu'):
     return g, flags, net.to(device).train()
 
 
+def reference_masks(g):
+    """ReLU masks of the REFERENCE's forward on the golden input, in call order (tools/make_golden.py records them)."""
+    keys = sorted(k for k in g.files if k.startswith('relu_mask/'))
+    out = []
+    for k in keys:
+        shape = tuple(int(v) for v in g['relu_shape/' + k[len('relu_mask/'):]])
+        out.append(torch.from_numpy(np.unpackbits(g[k])[:int(np.prod(shape))].reshape(shape).astype(bool)))
+    return out
+
+
+def mask_flips(masks_a, masks_b, pres=None):
+    """Entries in which two lists of ReLU masks differ; with `pres` (the pre-activations of one side) also the largest
+    |pre-activation| among them relative to the layer's rms -- a legitimate flip sits within fp32 rounding of zero."""
+    assert len(masks_a) == len(masks_b)
+    flips, total, worst = 0, 0, 0.0
+    for i, (a, b) in enumerate(zip(masks_a, masks_b)):
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        d = a != b
+        n = int(d.sum())
+        flips += n; total += a.numel()
+        if n and pres is not None:
+            p = pres[i].double()
+            worst = max(worst, float(p[d].abs().max() / max(float(p.pow(2).mean().sqrt()), 1e-30)))
+    return flips, total, worst
+
+
+@pytest.mark.parametrize('name', ['dense_cfg1_2d', 'dense_mini_3d'])
+def test_dense_cpu_route_gradients_with_reference_masks(name):
+    """CPU route against the golden vectors with its ReLU branches pinned to the REFERENCE's own masks (recorded by
+    tools/make_golden.py from the imported reference model): what is left is arithmetic, and every golden gradient holds
+    to 5e-5 (the unpinned comparison above needs 2e-4 because single pre-activations within fp32 rounding of zero flip).
+    The route's own masks differ from the reference's in at most a handful of entries, all within rounding of zero."""
+    from uresnet_pytorch_amd import dense_ops as D
+    g, flags, net = load(name)
+    x = torch.from_numpy(g['input']); lab = torch.from_numpy(g['label'])
+    ref_m = reference_masks(g)
+    own, pres = [], []
+
+    def free_relu(pre):
+        own.append(pre.detach() > 0); pres.append(pre.detach().clone())
+        return torch.relu(pre)
+    D.RELU_OVERRIDE = free_relu
+    try:
+        net(x)
+    finally:
+        D.RELU_OVERRIDE = None
+    flips, total, worst = mask_flips(own, ref_m, pres)
+    assert flips <= max(4, int(2e-6 * total)) and worst < 1e-5, (flips, total, worst)
+    it = iter(ref_m)
+    D.RELU_OVERRIDE = lambda pre: pre * next(it).to(pre.dtype)
+    try:
+        logits = net(x)
+        loss, acc = DenseSegmentationLoss(flags)(list(logits), list(x), list(lab), None)
+        net.zero_grad(); loss.backward()
+    finally:
+        D.RELU_OVERRIDE = None
+    assert next(it, None) is None
+    assert rel(logits.detach().numpy(), g['logits']) < TOL
+    assert abs(loss.item() - float(g['loss'])) < TOL * abs(float(g['loss']))
+    worst_g = 0.0
+    for k in g.files:
+        if k.startswith('grad/'):
+            p = dict(net.named_parameters())[k[5:]]
+            e = rel(p.grad.numpy(), g[k]); worst_g = max(worst_g, e)
+            assert e < 5 * TOL, (k, e)
+    print('%s: %d of %d mask entries differ from the reference (|pre|/rms <= %.1e); pinned gradients %.1e'
+          % (name, flips, total, worst, worst_g))
+
+
 @pytest.mark.parametrize('name', ['dense_cfg1_2d', 'dense_mini_3d'])
 def test_dense_model_matches_reference_golden(name):
     g, flags, net = load(name)
@@ -48,7 +117,7 @@ def test_dense_model_matches_reference_golden(name):
     for k in g.files:
         if k.startswith('grad/'):
             p = dict(net.named_parameters())[k[5:]]
-            assert rel(p.grad.numpy(), g[k]) < 20 * TOL, k     # grads through ~30 BN layers
+            assert rel(p.grad.numpy(), g[k]) < TOL, k     # (bitwise equal here: the CPU route issues the reference's own ATen ops)
     loss_w, acc_w = crit(list(net(x)), list(x), list(lab), list(w))
     assert abs(loss_w.item() - float(g['loss_w'])) < TOL * abs(float(g['loss_w']))
 
@@ -65,26 +134,36 @@ def test_dense_model_gpu_route_matches_reference_golden(name):
     """Same golden vectors through the GPU route (dense_hip.py: gather-conv + BN HIP kernels via the C ABI)."""
     assert torch.cuda.is_available()
     dev = torch.device('cuda:0')
+    from uresnet_pytorch_amd import dense_ops as D
     g, flags, net = load(name, dev)
     x = torch.from_numpy(g['input']).to(dev); lab = torch.from_numpy(g['label']).to(dev)
-    logits = net(x)
+    masks = []
+    D.RELU_RECORD = lambda y: masks.append((y > 0).cpu())
+    try:
+        logits = net(x)
+    finally:
+        D.RELU_RECORD = None
     assert rel(logits.detach().cpu().numpy(), g['logits']) < 2 * TOL
     crit = DenseSegmentationLoss(flags)
     loss, acc = crit(list(logits), list(x), list(lab), None)
     assert abs(loss.item() - float(g['loss'])) < 2 * TOL * abs(float(g['loss']))
     assert abs(acc - float(g['acc'])) < 1e-6
     loss.backward()
-    # End-to-end gradients against the golden vectors are only held loosely here (3e-2): a pre-activation within fp32
-    # rounding of zero flips its ReLU mask between the reference's ATen evaluation order and this one, and with 8k..130k
-    # rows per layer one flip moves a per-channel gradient sum by ~1e-2.  The tight check is
-    # test_dense_gpu_gradients_with_pinned_masks below (same masks on both sides: 2e-5), and the CPU route is held to the
-    # golden gradients at 2e-4 above.
     worst = 0.0
     for k in g.files:
         if k.startswith('grad/'):
             p = dict(net.named_parameters())[k[5:]]
             worst = max(worst, rel(p.grad.cpu().numpy(), g[k]))
-    assert worst < 3e-2, worst
+    # ReLU branches of this forward against the REFERENCE's own (recorded in the golden file).  A pre-activation within
+    # fp32 rounding of zero may take the other branch in a different evaluation order, and with 8k..130k rows per layer
+    # one such flip moves a per-channel gradient sum by ~1e-2: the direct comparison with the golden gradients is therefore
+    # tight (5e-5) exactly when no branch differs, and otherwise bounded by the flip count; the arithmetic is held to 2e-5
+    # in either case by test_dense_gpu_gradients_with_pinned_masks (GPU vs CPU route on the GPU's masks) chained to
+    # test_dense_cpu_route_gradients_with_reference_masks (CPU route vs golden on the reference's masks, 5e-5).
+    flips, total, _ = mask_flips(masks, reference_masks(g))
+    print('%s: GPU route vs reference: %d of %d ReLU branches differ, worst golden gradient error %.2e' % (name, flips, total, worst))
+    assert flips <= max(4, int(2e-6 * total)), (flips, total)
+    assert worst < (5 * TOL if flips == 0 else 3e-2), (worst, flips)
 
 
 def run_pinned(cpu, gpu, x, lab, crit, dev):
@@ -98,6 +177,26 @@ def run_pinned(cpu, gpu, x, lab, crit, dev):
         out_g = gpu(xg); loss_g, acc_g = crit(list(out_g), list(xg), list(lg), None); loss_g.backward()
     finally:
         D.RELU_RECORD = None
+    # the CPU route on its OWN branches first: forward, loss and accuracy are compared unpinned, and the GPU's masks may
+    # differ from the CPU route's own only in a handful of entries whose pre-activation is within rounding of zero (a wrong
+    # scale / shift on the GPU side would flip thousands and must not be copied into the reference run unnoticed)
+    own, pres = [], []
+
+    def free_relu(pre):
+        own.append(pre.detach() > 0); pres.append(pre.detach().clone())
+        return torch.relu(pre)
+    D.RELU_OVERRIDE = free_relu
+    try:
+        with torch.no_grad():
+            out_f = cpu(x); loss_f, acc_f = crit(list(out_f), list(x), list(lab), None)
+    finally:
+        D.RELU_OVERRIDE = None
+    flips, total, worst_pre = mask_flips(masks, own, pres)
+    print('pinned run: %d of %d ReLU branches differ from the CPU route\'s own (|pre|/rms <= %.1e)' % (flips, total, worst_pre))
+    assert flips <= max(8, int(1e-5 * total)) and worst_pre < 1e-4, (flips, total, worst_pre)
+    assert rel(out_g.detach().cpu().numpy(), out_f.numpy()) < 2 * TOL
+    assert abs(loss_g.item() - loss_f.item()) < 2 * TOL * abs(loss_f.item())
+    assert abs(float(acc_g) - float(acc_f)) < 1e-4
     it = iter(masks)
     D.RELU_OVERRIDE = lambda pre: pre * next(it).to(pre.dtype)
     try:

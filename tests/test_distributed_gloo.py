@@ -117,3 +117,49 @@ def test_lpt_sharding_is_used_by_the_trainer_and_replicas_stay_in_sync():
     assert [s0, s1] == parallel.shard_events([256] * 5, 2)
     assert np.array_equal(pa, pb)                     # rank-identical parameters after the step
     assert abs(la - lb) < 1e-12
+
+
+def _worker_idle(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from uresnet_pytorch_amd.trainval import trainval
+    torch.manual_seed(100 + rank)            # as _worker: rank 0's initialisation is what everybody gets
+    t = trainval(_flags())
+    t.initialize()
+    p0 = torch.cat([p.detach().flatten() for p in t._net.parameters()]).clone()
+    res = t.train_step(_blob(), epoch=0., batch_size=2)     # TWO events, THREE ranks: one rank owns nothing
+    g = t._grads.flat.clone()
+    p1 = torch.cat([p.detach().flatten() for p in t._net.parameters()]).clone()
+    q.put((rank, list(t.last_slots), p0.numpy(), g.numpy(), p1.numpy(), res['loss_seg'], res['accuracy'],
+           len(res['segmentation'])))
+    torch.distributed.destroy_process_group()
+
+
+def test_rank_without_an_entry_contributes_zero_gradients():
+    """Fewer events than ranks (shard_events([n, n], 3) -> [[0], [1], []]): the idle rank must not raise, contributes zeros
+    to the gradient sum, takes part in the collective and the optimizer step, and ends with the same parameters."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_idle, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs: p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o[0])
+    for p in procs: p.join(60)
+    slots = [o[1] for o in outs]
+    assert slots == [[0], [1], []]
+    assert outs[2][7] == 0                                                  # no segmentation entries on the idle rank
+    for o in outs[1:]:
+        assert np.array_equal(o[3], outs[0][3])                             # the same summed gradient everywhere
+        assert np.array_equal(o[4], outs[0][4])                             # replicas in sync after the step
+        assert abs(o[5] - outs[0][5]) < 1e-12 and abs(o[6] - outs[0][6]) < 1e-12
+    assert not np.array_equal(outs[0][2], outs[0][4])                       # the step did move the parameters
+    # equal to the two-rank run of the same blob (the idle rank adds exactly zero)
+    q2 = ctx.Queue()
+    port2 = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port2, q2)) for r in range(2)]
+    for p in procs: p.start()
+    two = sorted([q2.get(timeout=240) for _ in procs], key=lambda o: o[0])
+    for p in procs: p.join(60)
+    assert np.array_equal(two[0][1], outs[0][2])                            # same initial parameters (seeded)
+    assert np.allclose(two[0][2], outs[0][3], rtol=1e-6, atol=1e-8)

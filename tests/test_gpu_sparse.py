@@ -268,10 +268,29 @@ def run_network_parity_pinned(dev, S, m, L, nc, pc, lab, tol_fwd, tol_grad, seed
     loss.backward()
     masks = gpu_relu_masks(net, dev)
     assert len(masks) == sum(1 for k in P if k.endswith('.bias') and not k.startswith('linear')), 'one mask per BatchNorm'
+    # the oracle on its OWN ReLU branches first: the GPU logits are compared with this unpinned run as well, and the GPU's
+    # masks may differ from the oracle's own only in a handful of entries per layer, each with a pre-activation within
+    # rounding of zero -- a wrong scale / shift export that flipped thousands would otherwise be copied into the reference
     free = orc.SparseUResNetOracle(P, m, L, nc, S)
     free.keep_acts = True
-    free.forward(pc)
-    flips = sum(int(((free.acts[k] > 0) != masks[k]).sum()) for k in masks)
+    logits_free = free.forward(pc)
+    flips, worst_pre = 0, 0.0
+    for k in masks:
+        d = (free.acts[k] > 0) != masks[k]
+        n_k = int(d.sum())
+        flips += n_k
+        assert n_k <= 8, (k, n_k)
+        if n_k:
+            pre = free.pre[k].astype(np.float64)
+            r_k = float(np.abs(pre[d]).max() / max(np.sqrt((pre ** 2).mean()), 1e-30))
+            worst_pre = max(worst_pre, r_k)
+            assert r_k < 1e-4, (k, n_k, r_k)     # |pre-activation| / rms of the layer at every flipped entry
+    assert flips <= 64, flips
+    e_free = rel(out[0].detach().cpu().numpy(), logits_free)
+    assert e_free < tol_fwd, ('unpinned logits', e_free)
+    loss_free = orc.segmentation_loss(logits_free, pc, lab)[0]
+    assert abs(loss.item() - loss_free) < 1e-5 * max(1.0, abs(loss_free))
+    print('pinned parity: %d ReLU branches differ from the oracle\'s own (|pre|/rms <= %.1e), unpinned logits %.2e' % (flips, worst_pre, e_free))
     ref = orc.SparseUResNetOracle(P, m, L, nc, S)
     ref.masks = masks
     logits_ref = ref.forward(pc)
@@ -575,6 +594,46 @@ def test_trainval_sparse_gpu(dev, tmp_path):
         assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu()), k1
     r2 = t2.forward(data_blob, epoch=0., batch_size=2)  # eval mode: running statistics, per-layer path
     assert r2['segmentation'][0].shape == (1200, 5) and np.isfinite(r2['loss_seg'])
+
+
+def test_npz_reader_on_device_feeds_the_trainer(dev, tmp_path):
+    """-io npz_sparse with -iod (the per-GPU concat of a step's events on the device): the blob assembled in
+    HBM is bitwise the host-assembled one, and a trainer step on it gives bitwise the same loss and parameters."""
+    from uresnet_pytorch_amd.trainval import trainval
+    from uresnet_pytorch_amd.iotools import io_factory, array_io
+    from uresnet_pytorch_amd.iotools.synthetic import generate_event
+    events = []
+    for seed in range(4):
+        c, v, l = generate_event(seed, 64, 900 + 50 * seed)
+        events.append({'voxels': c, 'feature': v, 'label': l})
+    path = str(tmp_path / 'ev.npz')
+    array_io.write_sparse_npz(path, events)
+
+    def flags(on_device):
+        return SimpleNamespace(MODEL_NAME='uresnet_sparse', IO_TYPE='npz_sparse', INPUT_FILE=[path], DATA_KEYS=['data', 'label'],
+                               DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=3, SPATIAL_SIZE=64, NUM_CLASS=5,
+                               BN_MOMENTUM=0.9, TRAIN=True, GPUS=[0], LEARNING_RATE=1e-3, MODEL_PATH='', WEIGHT_PREFIX='',
+                               BATCH_SIZE=2, MINIBATCH_SIZE=2, SHUFFLE=0, LIMIT_NUM_SAMPLE=-1, IO_ON_DEVICE=on_device,
+                               COMPUTE_WEIGHT=False, OUTPUT_FILE='')
+    out = {}
+    for on_device in (False, True):
+        fl = flags(on_device)
+        io = io_factory(fl)
+        io.initialize()
+        idx, blob = io.next()
+        if on_device:
+            assert torch.is_tensor(blob['data'][0]) and blob['data'][0].is_cuda
+        torch.manual_seed(0)
+        t = trainval(fl)
+        t.initialize()
+        res = t.train_step({'data': [blob['data']], 'label': [blob['label']]}, epoch=0., batch_size=2)
+        host = lambda a: a.cpu().numpy() if torch.is_tensor(a) else a
+        out[on_device] = (host(blob['data'][0]), host(blob['label'][0]), res['loss_seg'],
+                          torch.cat([p.detach().flatten() for p in t._net.parameters()]).cpu().numpy())
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+    assert sorted(np.unique(out[True][0][:, 3]).tolist()) == [0.0, 1.0]
+    assert out[False][2] == out[True][2] and np.isfinite(out[True][2])
+    assert np.allclose(out[False][3], out[True][3], rtol=0, atol=1e-6)      # (weight-gradient atomics: last bits)
 
 
 def test_empty_and_tiny_inputs(dev):

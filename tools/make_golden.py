@@ -37,7 +37,22 @@ def make(name, dim, ss, uf, uns, nc, B, seed):
     rng = np.random.default_rng(seed)
     w = torch.from_numpy(rng.uniform(0.5, 2.0, size=blob['label'].shape).astype(np.float32))
     out = {}
-    logits = net(x)
+    # every ReLU output of the reference's forward, in call order (nn.ReLU and F.relu both end in torch.nn.functional.relu):
+    # the masks let the parity tests pin ReLU branches to the REFERENCE's own, so that gradients are compared as arithmetic
+    # (a pre-activation within fp32 rounding of zero takes either branch in any two evaluation orders)
+    import torch.nn.functional as F_
+    relu_masks = []
+    orig_relu = F_.relu
+
+    def recording_relu(inp, inplace=False):
+        y = orig_relu(inp, inplace=inplace)
+        relu_masks.append((y > 0).numpy().copy())
+        return y
+    F_.relu = recording_relu
+    try:
+        logits = net(x)
+    finally:
+        F_.relu = orig_relu
     loss, acc = crit(list(logits), list(x), list(lab), None)
     net.zero_grad(); loss.backward()
     grads = {k: p.grad.detach().numpy().copy() for k, p in net.named_parameters() if p.grad is not None}
@@ -53,6 +68,9 @@ def make(name, dim, ss, uf, uns, nc, B, seed):
         if k in keep:
             out['grad/' + k] = v
     out['grad_keys_with_grad'] = np.array(sorted(grads.keys()))
+    for i, mk in enumerate(relu_masks):
+        out['relu_mask/%03d' % i] = np.packbits(mk.reshape(-1))
+        out['relu_shape/%03d' % i] = np.array(mk.shape)
     out.update(dict(input=blob['data'], label=blob['label'], weight=w.numpy(), logits=logits.detach().numpy(),
                     loss=np.float64(loss.item()), acc=np.float64(acc), loss_w=np.float64(loss_w.item()),
                     acc_w=np.float64(acc_w), flags=np.array([dim, ss, uf, uns, nc, B])))

@@ -741,9 +741,10 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
                 }
                 a.slab = a.zc * a.zt > 1 ? (float *)scratch : nullptr;
                 const dim3 grid3((unsigned)tiles, gy3, a.zc * a.zt);
-                static bool attr3 = false;
+                // (one flag per instantiation: the attribute call is a host round trip into the runtime, ~100 of them per dense step otherwise)
 #define URN_D3(P, K, N, R) if (precision == P && kc3 == K && ncb == N && rev == R) { \
-                    if (!attr3) (void)hipFuncSetAttribute((const void *)k_dense_conv3<P, K, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    static bool attr_done = false; \
+                    if (!attr_done) { (void)hipFuncSetAttribute((const void *)k_dense_conv3<P, K, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
                     hipLaunchKernelGGL((k_dense_conv3<P, K, N, R>), grid3, dim3(512), lds3, st, a); \
                     if (a.slab) hipLaunchKernelGGL(k_dense_splitk_reduce, dim3(reduce_blocks), dim3(256), 0, st, a, a.zc * a.zt); \
                     URN_LAUNCH_CHECK(); return URN_OK; }
@@ -1231,9 +1232,9 @@ extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *d
         const int nci = cin >= 32 ? 2 : 1, nco = cout >= 32 ? 2 : 1;
         const bool full = (cin % 32 == 0 || cin == 16) && (cout % 32 == 0 || cout == 16);
         if (ntap == 27 && stride == 1 && a.NRB == 16 && a.TY == 4 && a.TZ == 4 && full) {
-            static bool attr3 = false;
 #define URN_DW3(P, I, C) if (precision == P && nci == I && nco == C) { \
-                if (!attr3) (void)hipFuncSetAttribute((const void *)k_dense_dw3<P, I, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                static bool attr_done = false; \
+                if (!attr_done) { (void)hipFuncSetAttribute((const void *)k_dense_dw3<P, I, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
                 hipLaunchKernelGGL((k_dense_dw3<P, I, C>), grid, block, lds, st, a); done = true; }
             URN_DW3(0, 1, 1) URN_DW3(0, 1, 2) URN_DW3(0, 2, 1) URN_DW3(0, 2, 2) URN_DW3(1, 1, 1) URN_DW3(1, 1, 2) URN_DW3(1, 2, 1) URN_DW3(1, 2, 2)
 #undef URN_DW3

@@ -43,6 +43,8 @@ class URESNET_FLAGS:
     PRECISION = 'fp32'
     LOSS_SCALE = 1.0
     GRAPH = False
+    CKPT_MODULE_PREFIX = False
+    IO_ON_DEVICE = False
     NUM_CHANNEL = -1
     ITERATION = 10000
     REPORT_STEP = 100
@@ -101,6 +103,13 @@ class URESNET_FLAGS:
         a('-graph', '--graph', action='store_true', default=self.GRAPH,
           help='dense model on the GPU: replay the training step (forward + loss + backward) from a captured HIP graph '
                '(one sub-step of fixed shape per iteration; anything else runs eagerly)')
+        a('-iod', '--io_on_device', action='store_true', default=self.IO_ON_DEVICE,
+          help='array-backed IO (-io npz_sparse / npz_dense): keep the file arrays in GPU memory and assemble every per-GPU '
+               'blob entry there (no host concatenation, no H2D copy per step)')
+        a('-cmp', '--ckpt_module_prefix', action='store_true', default=self.CKPT_MODULE_PREFIX,
+          help="write checkpoints with the reference's DataParallel key prefix ('module.<name>', reference "
+               "trainval.py:37,181) so that they load into the reference with strict=False; checkpoints with or without "
+               "the prefix are both read")
         return parser
 
     def _build_parsers(self):
@@ -150,6 +159,11 @@ class URESNET_FLAGS:
         self.GPUS = list(range(len(self.GPUS.split(',')))) if len(self.GPUS) > 0 else []
         self.INPUT_FILE = [str(f) for f in self.INPUT_FILE.split(',')]
         self.DATA_KEYS = self.DATA_KEYS.split(',')
+        ls = float(getattr(self, 'LOSS_SCALE', 1.0) or 1.0)
+        if not (ls > 0 and np.isfinite(ls) and np.frexp(ls)[0] == 0.5):
+            sys.stderr.write('ERROR: -ls / --loss_scale must be a positive power of two (got %r): only then are scaling and '
+                             'unscaling exact\n' % ls)
+            raise ValueError
         self.SEED = int(self.SEED)
         if self.SEED < 0:
             self.SEED = int(time.time())

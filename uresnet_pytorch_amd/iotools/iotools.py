@@ -1,6 +1,7 @@
 """io_factory with the reference's contract (reference uresnet/iotools/iotools.py:5-10,
 io_base.py:7-67).  The LArCV/ROOT readers are out of scope (larcv and ROOT are absent);
-'synthetic_sparse' / 'synthetic_dense' serve the same blob layout from the seeded generator:
+'npz_sparse' / 'npz_dense' (array_io.py) read plain array files; 'synthetic_sparse' / 'synthetic_dense' serve the same blob
+layout from the seeded generator:
     next() -> (idx_per_gpu, blob), blob[data_key][gpu] = (N, d+2) [coords.., batch_id, value]
     (reference iotools_sparse.py:141,152-160), blob[label_key][gpu] = (N, 1), optional
     '_weights_' class balancing (reference :311-318); dense (B? , C, [D,] H, W) per entry.
@@ -101,7 +102,11 @@ def io_factory(flags):
         return io_synthetic_sparse(flags)
     if flags.IO_TYPE in ('synthetic_dense',):
         return io_synthetic_dense(flags)
+    if flags.IO_TYPE in ('npz_sparse', 'npz_dense'):
+        # array-backed readers with the same blob contract (array_io.py): real data without LArCV/ROOT
+        from . import array_io
+        return (array_io.io_npz_sparse if flags.IO_TYPE == 'npz_sparse' else array_io.io_npz_dense)(flags)
     if flags.IO_TYPE in ('larcv_sparse', 'larcv_dense'):
         raise NotImplementedError('LArCV/ROOT readers are out of scope of this build (larcv is not installed); '
-                                  'use -io synthetic_sparse / synthetic_dense')
+                                  'use -io npz_sparse / npz_dense (array files) or synthetic_sparse / synthetic_dense')
     raise NotImplementedError

@@ -152,8 +152,9 @@ def log_metrics(handlers, flags, data_blob, res):
     if getattr(handlers, 'metrics_logger', None) is None:
         handlers.metrics_logger = utils.CSVData('%s/inference_metrics-%07d.csv' % (flags.LOG_DIR, handlers.iteration))
     lg = handlers.metrics_logger
-    data_v = [d for sub in data_blob['data'] for d in sub]
-    label_v = [d for sub in data_blob['label'] for d in sub]
+    host = lambda a: a.detach().cpu().numpy() if torch.is_tensor(a) else a     # (-iod: the blob lives on the device)
+    data_v = [host(d) for sub in data_blob['data'] for d in sub]
+    label_v = [host(d) for sub in data_blob['label'] for d in sub]
     soft_v = list(res['softmax'])
     if 'sparse' in flags.MODEL_NAME:
         m, _ = utils.compute_metrics_sparse(data_v, label_v, soft_v, None, N=flags.SPATIAL_SIZE)
@@ -178,6 +179,13 @@ def inference_loop(flags, handlers):
         data_blob = get_data_minibatched(handlers, flags, data_key, label_key, weight_key)
         res = handlers.trainer.forward(data_blob, epoch=float(epoch), batch_size=flags.BATCH_SIZE)
         log_metrics(handlers, flags, data_blob, res)
+        # Store output if requested (reference :248-249); readers without a writer (synthetic) have no store_segment
+        if flags.OUTPUT_FILE and hasattr(handlers.data_io, 'store_segment') and handlers.trainer._world == 1:
+            at = 0
+            for sub, idx in enumerate(data_blob['idx_v']):
+                n_entries = len(data_blob['data'][sub])
+                handlers.data_io.store_segment(idx, data_blob['data'][sub], res['softmax'][at:at + n_entries])
+                at += n_entries
         tspent_iteration = time.time() - tstart_iteration
         tsum += tspent_iteration
         log(handlers, tstamp_iteration, tspent_iteration, tsum, res, flags, epoch)

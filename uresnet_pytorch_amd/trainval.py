@@ -34,24 +34,39 @@ class trainval(object):
         total_loss = 0.0
         for loss in self._loss:
             total_loss = total_loss + loss
-        total_loss = total_loss / len(self._loss)
+        total_loss = total_loss / max(len(self._loss), 1)
         self._loss = []
         self._grads.zero()
+        # a rank that owned no entry in any sub-step (fewer events than ranks: shard_events([5], 3) -> [[0], [], []]) has no
+        # graph to differentiate: it contributes ZERO gradients to the sum and still takes part in the collective and the
+        # optimizer step, so that the replicas stay identical
+        has_graph = torch.is_tensor(total_loss) and total_loss.requires_grad
         # loss scaling (flags -ls, a power of two): the backward pass is linear in the incoming gradient, so scaling the
         # loss scales every gradient operand -- with -prec fp16 the unscaled ones (1e-6 .. 1e-8 at cfg5 size) fall below
         # fp16's range when they are rounded for the matrix cores; the flat gradient buffer is unscaled in one pass
         scale = float(getattr(self._flags, 'LOSS_SCALE', 1.0) or 1.0)
+        if has_graph:
+            if scale != 1.0:
+                total_loss = total_loss * scale
+            total_loss.backward()
+            if scale != 1.0:
+                self._grads.flat.mul_(1.0 / scale)
+        # SUM over ranks (the reference loss is a sum over all events): ONE collective over the flat buffer, issued behind
+        # the backward kernels on the caller's stream and complete (stream-ordered) before the optimizer reads the gradients.
+        # (No overlap with the backward pass is claimed here: the buffer is complete only after the weight gradients of the
+        # side stream have been joined.  N > 1 over RCCL is unmeasured on hardware so far -- DESIGN section 5.)
+        self._grads.all_reduce()
+        self.skipped_step = False
         if scale != 1.0:
-            total_loss = total_loss * scale
-        total_loss.backward()
-        if scale != 1.0:
-            self._grads.flat.mul_(1.0 / scale)
-        # SUM over ranks (the reference loss is a sum over all events): ONE collective over the flat buffer, started
-        # asynchronously behind the backward kernels (RCCL waits for the stream's event on its own stream) and joined
-        # right before the optimizer reads the gradients
-        work = self._grads.all_reduce(async_op=True)
-        if work is not None:
-            work.wait()
+            # loss scaling: an operand that overflowed at this scale leaves inf / NaN in the gradients, and Adam's moments
+            # would keep it for good.  Checked AFTER the all-reduce (a non-finite value survives the sum, so every rank takes
+            # the same decision); one host read-back, on the scaled (-prec fp16) path only
+            if not bool(torch.isfinite(self._grads.flat).all()):
+                self.skipped_step = True
+                self.skipped_steps = getattr(self, 'skipped_steps', 0) + 1
+                sys.stderr.write('WARNING: non-finite gradients at loss scale %g: optimizer step skipped (%d so far); '
+                                 'lower -ls\n' % (scale, self.skipped_steps))
+                return
         self._optimizer.step()
 
     # -- reference trainval.py:32-40
@@ -94,7 +109,13 @@ class trainval(object):
         loss, acc = self._gstep(data, label, weight)
         if scale != 1.0:
             self._grads.flat.mul_(1.0 / scale)
-        self._optimizer.step()
+        self.skipped_step = False
+        if scale != 1.0 and not bool(torch.isfinite(self._grads.flat).all()):   # as in backward(): no step on overflow
+            self.skipped_step = True
+            self.skipped_steps = getattr(self, 'skipped_steps', 0) + 1
+            sys.stderr.write('WARNING: non-finite gradients at loss scale %g: optimizer step skipped\n' % scale)
+        else:
+            self._optimizer.step()
         self.last_slots = list(range(data.shape[0]))
         out = self._gstep.out
         return {'segmentation': [out[i].detach().clone() for i in range(out.shape[0])], 'accuracy': [acc.clone()],
@@ -166,6 +187,13 @@ class trainval(object):
         with torch.set_grad_enabled(self._flags.TRAIN):
             data = [torch.as_tensor(data[i]).to(self._device) for i in slots]
             tstart = time.time()
+            if not slots:
+                # no entry of this sub-step is ours: nothing to run; the loss term is a plain 0 (see backward())
+                if label is not None and self._flags.TRAIN:
+                    self._loss.append(0.)
+                self.tspent['forward'] = time.time() - tstart
+                self.tspent_sum['forward'] += self.tspent['forward']
+                return {'segmentation': [], 'accuracy': [0.], 'loss_seg': [0.]}
             if sparse:
                 segmentation = []
                 for d in data:
