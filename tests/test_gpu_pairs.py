@@ -266,6 +266,7 @@ def test_pairs_fragment_ordered_weights_give_the_same_bits(dev, cin, cout):
     pl = geo.pairs['nbr'][0]
     outs = []
     L.urn_set_option(b'pairs_max_cin', 999)      # both calls on the pair-list kernel (without fragments cin > 80 takes the tile kernel)
+    L.urn_set_option(b'pairs_v3', 0)             # ... and on the same loop (the strip variant needs the fragments and accumulates in another order)
     for frag in (None, wf):
         y = torch.empty(n, cout, device=dev)
         a = _l.GConvArgs()
@@ -275,6 +276,7 @@ def test_pairs_fragment_ordered_weights_give_the_same_bits(dev, cin, cout):
         _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
         outs.append(y)
     L.urn_set_option(b'pairs_max_cin', 80)
+    L.urn_set_option(b'pairs_v3', 0x17E)
     assert torch.equal(outs[0], outs[1])
 
 
@@ -352,6 +354,7 @@ def test_pairs_ring_variant_gives_the_same_bits(dev, cin, cout):
     pl = geo.pairs['nbr'][0]
     outs = {}
     try:
+        L.urn_set_option(b'pairs_v3', 0)     # (the strip variant takes precedence over the ring)
         for bits in (0, 30):
             L.urn_set_option(b'pairs_deep', bits)
             for xf in (False, True):
@@ -365,6 +368,63 @@ def test_pairs_ring_variant_gives_the_same_bits(dev, cin, cout):
                 outs[(bits, xf)] = y
     finally:
         L.urn_set_option(b'pairs_deep', 0)
+        L.urn_set_option(b'pairs_v3', 0x17E)
     for xf in (False, True):
         assert torch.equal(outs[(0, xf)], outs[(30, xf)]), (cin, cout, xf)
     assert not torch.equal(outs[(0, False)], outs[(0, True)])
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 16), (32, 32), (48, 48), (64, 64), (80, 80), (96, 48), (128, 64), (32, 16), (16, 32)])
+def test_pairs_strip_variant(dev, cin, cout):
+    """urn_set_option("pairs_v3", bits), the default loop of the pair-list kernel for one-chunk inputs: the pair words of a wave's
+    share staged in a wave-private LDS strip, the next offset's weight block requested with the next rows, the old slab values
+    as the MFMA's C operand.  Another summation order than the per-block index loop (old + (acc + acc2) there), so: within
+    1e-6 of it, within 1e-5 of the fp64 product, bitwise reproducible from run to run, with and without the folded input
+    BatchNorm, on 64-row tiles with a share per wave of one to many blocks (pairs_split 1 / 8)."""
+    from uresnet_pytorch_amd import lib as _l, sparse_ops as so
+    L = _l.load()
+    S = 32
+    c, f = cloud(19, S, 2500, 2)
+    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
+    n = geo.n[0]
+    g = torch.Generator(device='cpu').manual_seed(cin * 5 + cout)
+    x = torch.randn(n, cin, generator=g).to(dev)
+    wt = (torch.randn(27, cout, cin, generator=g) * 0.1).to(dev)
+    sc = (torch.rand(cin, generator=g) + 0.5).to(dev); sh = (torch.randn(cin, generator=g) * 0.1).to(dev)
+    wf = torch.empty_like(wt)
+    _l.check(L.urn_weight_fragments(wt.data_ptr(), 27, cout, cin, wf.data_ptr(), _l.stream()), 'weight_fragments')
+    pl = geo.pairs['nbr'][0]
+
+    def call(xf):
+        y = torch.empty(n, cout, device=dev)
+        a = _l.GConvArgs()
+        a.x = x.data_ptr(); a.wt = wt.data_ptr(); a.tbl = geo.nbr[0].data_ptr(); a.ld = geo.ld; a.K = 27; a.flip = 0; a.n_out = n
+        a.cin = cin; a.cout = cout; a.y = y.data_ptr(); a.pairs = pl[0].data_ptr(); a.pairs_tile = pl[1]; a.wt_frag = wf.data_ptr()
+        if xf:
+            a.xf_scale = sc.data_ptr(); a.xf_shift = sh.data_ptr()
+        _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
+        return y
+    nbr = geo.nbr[0][:, :n].cpu().numpy()
+    wd = wt.double().cpu().numpy()
+    refs = {}
+    for xf in (False, True):
+        xd = (torch.relu(x.double() * sc.double() + sh.double()) if xf else x.double()).cpu().numpy()
+        ref = np.zeros((n, cout))
+        for k in range(27):
+            m = nbr[k] >= 0
+            ref[m] += xd[nbr[k][m]] @ wd[k].T
+        refs[xf] = ref
+    try:
+        L.urn_set_option(b'pairs_max_cin', 999)
+        for split in (0, 1, 8):
+            L.urn_set_option(b'pairs_split', split)
+            for xf in (False, True):
+                L.urn_set_option(b'pairs_v3', 0)
+                y_loop = call(xf)
+                L.urn_set_option(b'pairs_v3', 0x17E)
+                y_a, y_b = call(xf), call(xf)
+                assert torch.equal(y_a, y_b), 'strip variant not bitwise reproducible'
+                assert rel(y_a.cpu().numpy(), refs[xf]) < TOL, (cin, cout, split, xf, rel(y_a.cpu().numpy(), refs[xf]))
+                assert rel(y_a.cpu().numpy(), y_loop.cpu().numpy()) < 1e-6, (cin, cout, split, xf)
+    finally:
+        L.urn_set_option(b'pairs_split', 0); L.urn_set_option(b'pairs_v3', 0x17E); L.urn_set_option(b'pairs_max_cin', 80)

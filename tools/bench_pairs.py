@@ -62,16 +62,19 @@ for kind, lv, ci, co in shapes:
         variants = [('cbg%d/nc%d/G%d' % (cb, nc, G), nc, G, cb) for cb in (0, 1, 2) for nc in (1, 2) for G in (2, 8)]
     if mode == 'deep':
         variants = [('one set', 0, 0, 0, 0), ('three sets', 0, 0, 0, 14)]
+    if mode == 'v3':
+        variants = [('loop', 0, 0, 0, 2, 0), ('strip', 0, 0, 0, 2, 0x17E), ('strip nc2', 2, 0, 0, 2, 0x17E)]
     if mode == 'sweep':
         variants += [('nc%d/G%d' % (nc, G), nc, G) for nc in (1, 2) for G in (2, 4, 8)]
-    use_frag = mode in ('sweep', 'abl')
+    use_frag = mode in ('sweep', 'abl', 'v3')
     for name, nc, G, *rest in variants:
         L.urn_set_option(b'pairs_cbg', rest[0] if rest else 0)
         L.urn_set_option(b'pairs_deep', rest[1] if len(rest) > 1 else 1)
+        L.urn_set_option(b'pairs_v3', rest[2] if len(rest) > 2 else 0x17E)
         L.urn_set_option(b'gconv_dbg', -nc if nc < 0 else 0)
         L.urn_set_option(b'pairs_nc', max(nc, 0)); L.urn_set_option(b'pairs_split', G)
         out.append('%s %.0f' % (name, min(run(kind, lv, ci, co, True, frag=use_frag) for _ in range(3))))
-    L.urn_set_option(b'pairs_nc', 0); L.urn_set_option(b'pairs_split', 0); L.urn_set_option(b'gconv_dbg', 0); L.urn_set_option(b'pairs_cbg', 0)
+    L.urn_set_option(b'pairs_nc', 0); L.urn_set_option(b'pairs_split', 0); L.urn_set_option(b'gconv_dbg', 0); L.urn_set_option(b'pairs_cbg', 0); L.urn_set_option(b'pairs_v3', 0x17E)
     out.append('frag %.0f' % min(run(kind, lv, ci, co, True, frag=True) for _ in range(3)))
     out.append('xf: tile %.0f pairs %.0f' % (min(run(kind, lv, ci, co, False, xf=True) for _ in range(2)),
                                              min(run(kind, lv, ci, co, True, xf=True) for _ in range(2))))

@@ -24,6 +24,13 @@
 #include <string.h>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// timing-only ablation switches (urn_set_option "gconv_dbg"; tools/bench_pairs.py abl) exist in -DURN_DIAG builds only
+// (make EXTRA=-DURN_DIAG): the product kernels carry no diagnostic branch
+#ifdef URN_DIAG
+#define URN_DBG(g, bits) ((g).dbg & (bits))
+#else
+#define URN_DBG(g, bits) 0
+#endif
 #define URN_PAIRS_IDXB 24   // blocks per chunk of the wave-private pair-word strip in LDS (DEEP variants)
 
 // ------------------------------------------------------------------------------------------------ list builder
@@ -156,7 +163,7 @@ __device__ __forceinline__ f32x4 pairs_mfma16(urn_s16x4 a, urn_s16x4 b, f32x4 c)
 // (register estimate of the loop: rows as loaded + operand registers 8 KC, weight fragments 4 KC NC)
 #define URN_PAIRS_REGS(KC, NC, PREC) ((KC) * ((NC) + 2) * 4)
 template <int KC, int NC, int XF, int DEEP, int PREC = 0>
-__global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64 ? 1024 : 512, (KC <= 2 && NC == 1 && DEEP == 0) ? 5 : 1) void k_gconv_pairs(GArgs g)
+__global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) <= 64 ? 1024 : 512, (KC <= 2 && NC == 1 && DEEP != 1) ? 5 : 1) void k_gconv_pairs(GArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // diagnostics, compiled only with -DURN_PAIRS_STAMP (make CXXFLAGS+=...): s_memtime at the phase boundaries of every wave
@@ -209,7 +216,8 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
     // 32-bit VGPR -- one v_mad_u32_u24 per gathered row, nothing per pair word or weight block.  (Anything derived from
     // threadIdx is divergent to the compiler, also the wave number: made scalar with readfirstlane once.)
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)g.x, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)g.pairs, 0, -1, 0x00020000);
+    // (the list's descriptor is bounded: the strip variant fills whole 16-block pieces, which may reach past the last tile's record -- zeros)
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)g.pairs, 0, ident ? 0 : (int)((long)gridDim.x * urn_pairs_words(K, T) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)g.wfrag, 0, -1, 0x00020000);
     const int pw_t = (int)((long)tile * urn_pairs_words(K, T)) + URN_PAIRS_HDR;   // word index of blk_t[0] / blk_p[0] in g.pairs
     const int pw_p = pw_t + (int)urn_pairs_tpad(K, T);
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
     const int b0 = __builtin_amdgcn_readfirstlane(nblk * gi / G);
     // (g.dbg: timing-only ablations of whole phases, tools/bench_pairs.py abl: 32 = no block loop, 64 = return before the epilogue,
     //  128 = one block per wave)
-    const int b1 = __builtin_amdgcn_readfirstlane((g.dbg & 32) ? b0 : ((g.dbg & 128) ? min(b0 + 1, nblk * (gi + 1) / G) : nblk * (gi + 1) / G));   // nblk <= 27 * 8, G <= 16
+    const int b1 = __builtin_amdgcn_readfirstlane(URN_DBG(g, 32) ? b0 : (URN_DBG(g, 128) ? min(b0 + 1, nblk * (gi + 1) / G) : nblk * (gi + 1) / G));   // nblk <= 27 * 8, G <= 16
 
     // GATHER MAPPING.  The MFMA wants lane (r, q) to hold channels 4q..4q+3 of pair r -- but a wave-load in that shape costs the
     // CU ~66 cycles whatever the cache level (tools/ubench/gather_map.hip): the texture addresser takes the lanes four at a time,
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
         const int so = (pw_p + b * 16) * 4;   // scalar (b is)
         pv = __builtin_amdgcn_raw_buffer_load_b32(rs_p, r * 4, so, 0);
         pl = __builtin_amdgcn_raw_buffer_load_b32(rs_p, gp * 4, so, 0);
-        tv = (g.dbg & 512) ? 0 : (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, 0, (pw_t + b) * 4, 0);   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
+        tv = URN_DBG(g, 512) ? 0 : (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, 0, (pw_t + b) * 4, 0);   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
     };
     // the first pair words of the wave's share are requested BEFORE the statistics of the folded BatchNorm are fetched and
     // finalized below: two round trips side by side instead of one after the other at the head of every folding launch
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
     wfrag_t w_cur[KC][NC];
     // (g.dbg 256: every pair gathers row 0 -- the loads stay, their cache lines collapse to one; 512: the weight block of offset 0
     //  for every block -- no reloads.  Timing only.)
-    const int row_mask = (g.dbg & 256) ? 0 : 0xFFFFFF;
+    const int row_mask = URN_DBG(g, 256) ? 0 : 0xFFFFFF;
     auto load_a = [&](f32x4 (&a)[KC], int pl, int ch) {
         const int vo = (int)__umul24((unsigned)(pl & row_mask), (unsigned)ldxb) + 16 * gq;
         const int so = ch * (64 * KC);
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
     };
 
     // (DEEP is a template parameter: the rotating sets cost registers in every instantiation that contains them)
-    if constexpr (DEEP != 0) {
+    if constexpr (DEEP == 1) {
         // RING variant (one channel chunk, cin = 16 KC; launcher: bit KC of `pairs_deep`).  The block loop is a latency chain per
         // wave: a step is ~0.1 us of MFMAs between a request and the ~0.7 us until it is served, and a step cannot start without
         // the weight block of its offset.  Three register sets for rows AND weight blocks rotate: step b multiplies set b % 3 and
@@ -436,6 +444,120 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
             }
         }
     }
+
+    if constexpr (DEEP == 2) {
+        // STRIP variant (one channel chunk: cin = 16 KC; launcher: bit KC of `pairs_v3`).  What a CU's vector-memory path can
+        // take is instructions, not bytes (any wave-wide load holds the address unit >= 16 cycles): the loop above issues
+        // three dword loads per block for the pair words and the table row next to KC row loads and KC * NC weight loads.
+        // Here the pair words and table rows of the wave's WHOLE share are copied once into a wave-private LDS strip with
+        // 16-byte loads (one per 16 blocks); per block the loop reads them back (ds_read_b32), so its vector-memory
+        // instructions are the gathered rows and the weight blocks only.  The weight block of the next block, when its
+        // offset differs, is requested together with the next block's rows BEFORE this block's MFMAs (second register set,
+        // copied over behind the MFMAs; KC <= 4) -- one round trip per block where the loop above has two dependent ones
+        // (weights at the head, rows at the tail).  The old slab values are the MFMA's C operand: no zero-fill, no adds.
+        // (16-byte aligned: the strips start at the next multiple of four words behind the epilogue's doubles; 17 p_strip words
+        //  per wave, p_strip a multiple of 16)
+        int *strip = (int *)smem + (((long)((int *)(s_p + 2 * (long)G * cw) - (int *)smem) + 3) & ~3L) + (long)wave * ((long)g.p_strip * 17);
+        int *strip_t = strip + (long)g.p_strip * 16;
+        const int nb = b1 - b0;
+        for (int c = 0; c < nb; c += 32) {      // wave-uniform; one pass for shares of up to 32 blocks
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const int so = (pw_p + (b0 + c) * 16) * 4;
+            i32x4 w0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane * 16, so, 0));
+            i32x4 w1 = w0;
+            if (c + 16 < nb) w1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane * 16, so + 1024, 0));
+            int tw = 0;
+            if (lane < 32 && c + lane < nb) tw = __builtin_amdgcn_raw_buffer_load_b32(rs_p, lane * 4, (pw_t + b0 + c) * 4, 0);
+            *(i32x4 *)(strip + c * 16 + lane * 4) = w0;
+            if (c + 16 < nb) *(i32x4 *)(strip + (c + 16) * 16 + lane * 4) = w1;
+            if (lane < 32 && c + lane < nb) strip_t[c + lane] = tw;
+        }
+        URN_STAMP(5);
+        if (nb > 0) {
+            constexpr bool W2 = KC * NC <= 4;     // second weight register set (16 KC NC bytes per lane)
+            constexpr bool XREG = XF != 0 && KC <= 3;
+            f32x4 xsc[XREG ? KC : 1], xsh[XREG ? KC : 1];
+            if constexpr (XREG) {
+#pragma unroll
+                for (int j = 0; j < KC; ++j) { xsc[j] = *(const f32x4 *)(s_xf + 16 * j + 4 * gq); xsh[j] = *(const f32x4 *)(s_xf + cin + 16 * j + 4 * gq); }
+            }
+            auto ready2 = [&](const f32x4 (&raw)[KC], wfrag_t (&dst)[KC]) {
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    f32x4 v = raw[j];
+                    if constexpr (XF != 0) {
+                        f32x4 sc, sh;
+                        if constexpr (XREG) { sc = xsc[j]; sh = xsh[j]; }
+                        else { sc = *(const f32x4 *)(s_xf + 16 * j + 4 * gq); sh = *(const f32x4 *)(s_xf + cin + 16 * j + 4 * gq); }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
+                    }
+                    if constexpr (PREC == 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float f = v[k];
+                            dst[j][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(f)));
+                        }
+                    } else {
+                        const uint2 h = urn_round16x4<PREC>(v);
+                        uint2 t;
+                        t.x = (unsigned)__builtin_amdgcn_ds_bpermute(bp_addr, (int)h.x);
+                        t.y = (unsigned)__builtin_amdgcn_ds_bpermute(bp_addr, (int)h.y);
+                        dst[j] = __builtin_bit_cast(urn_s16x4, t);
+                    }
+                }
+            };
+            wfrag_t w_nxt[W2 ? KC : 1][W2 ? NC : 1];
+            int t_c = __builtin_amdgcn_readfirstlane(strip_t[0]);
+            load_w(w_cur, t_c, 0);
+            load_a(a_nxt, strip[gp], 0);
+            int pv_c2 = strip[r];
+            const int i1 = nb > 1 ? 1 : 0;
+            int pv_n2 = strip[i1 * 16 + r], pl_n2 = strip[i1 * 16 + gp];
+            int t_n = __builtin_amdgcn_readfirstlane(strip_t[i1]);
+            ready2(a_nxt, a_cur);
+            for (int i = 0; i < nb; ++i) {
+                const int i2 = i + 2 < nb ? i + 2 : nb - 1;
+                float *dptr = slab + (long)((unsigned)pv_c2 >> 24) * LDW + 4 * q;
+                f32x4 acc[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = *(const f32x4 *)(dptr + 16 * c);
+                const int pv_nn = strip[i2 * 16 + r], pl_nn = strip[i2 * 16 + gp], tv_nn = strip_t[i2];
+                const bool more = i + 1 < nb;                 // wave-uniform
+                const bool chg = more && t_n != t_c;
+                if constexpr (W2) { if (chg) load_w(w_nxt, t_n, 0); }
+                if (more) load_a(a_nxt, pl_n2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PREC == 0) {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) acc[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc[c]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) acc[c] = pairs_mfma16<PREC>(w_cur[j][c], a_cur[j], acc[c]);
+                }
+                if constexpr (!W2) { if (chg) load_w(w_cur, t_n, 0); }      // (issued behind the MFMAs that read w_cur)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = acc[c];
+                if (more) ready2(a_nxt, a_cur);
+                if constexpr (W2) {
+                    if (chg) {
+#pragma unroll
+                        for (int j = 0; j < KC; ++j)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) w_cur[j][c] = w_nxt[j][c];
+                    }
+                }
+                pv_c2 = pv_n2; pv_n2 = pv_nn; pl_n2 = pl_nn;
+                t_c = t_n; t_n = __builtin_amdgcn_readfirstlane(tv_nn);
+            }
+        }
+    }
     if constexpr (DEEP == 0)
     // Steps s = (block, channel chunk).  The gathered rows of step s + 1 are requested before the MFMAs of step s and the
     // pair words three blocks ahead.  The weight fragments stay in registers while the offset (and chunk) does not
@@ -498,7 +620,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
         }
     }
     URN_STAMP(2);
-    if (g.dbg & 64) return;
+    if (URN_DBG(g, 64)) return;
     __syncthreads();
     URN_STAMP(3);
 
@@ -579,6 +701,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP ? 3 : 1) <= 64
             g.part[((long)tile * 2 + 1) * cout + col] = v1;
         }
     }
+    URN_STAMP(6);
 }
 
 
@@ -592,6 +715,13 @@ template <int KC, int NC, int PREC>
 static void launch_pairs16(const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
 {
     const bool xf = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
+    if constexpr (NC <= 2) {
+        if (a.p_deep == 2) {
+            if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 2, PREC>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 2, PREC>), grid, block, lds, st, a);
+            return;
+        }
+    }
     if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 0, PREC>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 0, PREC>), grid, block, lds, st, a);
 }
@@ -632,15 +762,21 @@ int g_pairs_split = 0;
 int g_pairs_split_kc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // force G for inputs of 16 KC channels (urn_set_option "pairs_split_kc<KC>"), 0 = automatic
 int g_pairs_wgs = 512;       // a workgroup takes several column groups only while the launch keeps this many workgroups ("pairs_wgs")
 int g_pairs_deep = 0;        // bit KC set: the RING variant (three rotating register sets for rows and weight blocks, two blocks in flight) for inputs of 16 KC channels, KC <= 4 (urn_set_option "pairs_deep").  Off: measured in the cfg3 step 2.690 ms without, 2.689 with it for KC 1, 2.70 for KC 1-2, 2.74 for KC 1-3, 2.86 for KC 1-4 -- with requests two blocks ahead (s_waitcnt vmcnt(8..9) in the ISA) the loop is no faster: it is not waiting for memory
+int g_pairs_v3 = 0x17E;       // bit KC set: the STRIP variant (pair words of a wave's share in LDS, weight block of the next offset requested with the next rows) for one-chunk inputs of 16 KC channels (urn_set_option "pairs_v3")
 int g_pairs_cbg = 0;          // most column groups per workgroup (urn_set_option "pairs_cbg"), 0 = as many as fit       // force G (urn_set_option "pairs_split"), 0 = automatic
 
 template <int KC, int NC>
 static void launch_pairs2(const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
 {
     const bool xf = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
+    if (a.p_deep == 2) {
+        if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 2>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 2>), grid, block, lds, st, a);
+        return;
+    }
     // DEEP variants exist for one-chunk inputs of up to 48 channels and one column block per wave
     if constexpr (KC <= 4 && NC == 1) {
-        if (a.p_deep) {
+        if (a.p_deep == 1) {
             if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 1>), grid, block, lds, st, a);
             else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 1>), grid, block, lds, st, a);
             return;
@@ -678,7 +814,8 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     }
     if (g_pairs_nc == 1 || (g_pairs_nc == 2 && nblk % 2 == 0 && (kc <= 6 || a.prec != 0)) || (g_pairs_nc == 4 && nblk % 4 == 0 && a.prec != 0)) nc = g_pairs_nc;
     const int cbg_all = nblk / nc;
-    const bool deep = a.prec == 0 && ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1 && kc <= 4 && a.pairs != nullptr && a.wfrag != nullptr;
+    const bool strip = ((g_pairs_v3 >> kc) & 1) && a.cin == 16 * kc && a.pairs != nullptr && a.wfrag != nullptr && nc <= 2;
+    const bool deep = !strip && a.prec == 0 && ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1 && kc <= 4 && a.pairs != nullptr && a.wfrag != nullptr;
     const int maxw = URN_PAIRS_REGS(kc, nc, a.prec) * (deep ? 3 : 1) <= 64 ? 16 : 8;   // waves per workgroup (register budget, see __launch_bounds__)
     // Workgroups first: the deep levels have few tiles (103 of 64 rows at level 3 of cfg3), and one workgroup per tile left
     // most of the 256 CUs idle (measured 56 -> 15 us at level 4, 80 -> 80, with one column group per workgroup): give a
@@ -689,9 +826,12 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
         if (cbg_all % d == 0 && (d == 1 || ntiles * (cbg_all / d) >= g_pairs_wgs)) { cbg = d; break; }
     if (g_pairs_cbg > 0 && cbg_all % g_pairs_cbg == 0 && g_pairs_cbg <= maxw) cbg = g_pairs_cbg;
     const int gy = cbg_all / cbg, cw = 16 * nc * cbg;
+    const int maxb = (int)urn_pairs_maxb(a.K, T);
+    auto strip_blocks = [&](int G) { return (((maxb + G - 1) / G + 1) + 15) & ~15; };   // longest share of a tile's block list, rounded up to whole 16-block fills
     auto lds_bytes = [&](int G) {
         size_t w = (size_t)2 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
-        return w * 4 + (size_t)2 * G * cw * 8 + (deep ? (size_t)cbg * G * URN_PAIRS_IDXB * 17 * 4 : 0);
+        return w * 4 + (size_t)2 * G * cw * 8 + (deep ? (size_t)cbg * G * URN_PAIRS_IDXB * 17 * 4 : 0) +
+               (strip ? (size_t)cbg * G * strip_blocks(G) * 17 * 4 + 16 : 0);
     };
     int G = 1;
     const int want_waves = (a.epi != 2 && g_pairs_waves_fwd > 0) ? g_pairs_waves_fwd : g_pairs_waves;
@@ -699,7 +839,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= 65536) G = g_pairs_split;
     if (kc <= 8 && g_pairs_split_kc[kc] > 0 && cbg * g_pairs_split_kc[kc] <= maxw && lds_bytes(g_pairs_split_kc[kc]) <= 65536) G = g_pairs_split_kc[kc];
     if (lds_bytes(G) > 65536) return 0;
-    a.p_split = G; a.p_cw = cw; a.p_deep = deep;   // bit KC of the option
+    a.p_split = G; a.p_cw = cw; a.p_deep = strip ? 2 : (deep ? 1 : 0); a.p_strip = strip ? strip_blocks(G) : 0;
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
     const size_t lds = lds_bytes(G);
 #define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs2<KCv, NCv>(a, grid, block, lds, st); return (int)ntiles; }
