@@ -248,24 +248,7 @@ typedef struct {
      * weight blocks of an offset in half the registers and take two to four column blocks per wave); any other
      * combination runs on the 2-D tile kernel. */
     int wt_frag_prec;
-    /* Optional (pair-list kernel, strip variant; urn_gconv_bn_fold_ok says whether a shape has it): the BatchNorm-backward
-     * APPLY pass folded into its consumer's gather.  The rows of x are then the ReLU-masked gradient g of a BatchNorm+ReLU
-     * output (what epilogue 2 of the producing call wrote) and every gathered element is used as that BatchNorm's INPUT
-     * gradient
-     *     gamma * invstd * (g - c0 - xhat * c1),  xhat = (bf_t - mean) * invstd,
-     * c0 / c1 = column means of g and g * xhat, taken from the accumulated slab bf_sums ([bf_slots][2][cin] doubles, the
-     * producing call's part / part_slots) over bf_n rows; bf_t = the BatchNorm's input, same row stride as x.  Workgroup 0
-     * adds the BatchNorm's parameter gradients (column sums of g * xhat and of g) into bf_dgamma / bf_dbeta. */
-    const float *bf_t;
-    const double *bf_sums;
-    int bf_slots;
-    int64_t bf_n;
-    const float *bf_gamma, *bf_mean, *bf_invstd;
-    float *bf_dgamma, *bf_dbeta;
 } urn_gconv_args;
-/* 1 when urn_gconv_fwd_ex runs a call of this shape (cin gathered channels, table height K, list tile, operand precision
- * 0 fp32 / 1 bf16 / 2 fp16) on the kernel variant that implements the bf_* fold, else 0 */
-int urn_gconv_bn_fold_ok(int cin, int cout, int K, int tile, int precision);
 /* wt (K, cout, cin) -> fragment order (see urn_gconv_args.wt_frag); cin, cout multiples of 16 */
 int urn_weight_fragments(const float *wt, int K, int cout, int cin, float *wt_frag, void *stream);
 /* the same with elements rounded (RNE) to bf16 (precision 1) or fp16 (2): K * cout * cin 16-bit words */
@@ -276,13 +259,6 @@ int urn_gconv_fwd_ex(const urn_gconv_args *args, int *n_part, void *stream);
 int urn_gconv_bwd_dw_ex(const float *x, const float *xf_scale, const float *xf_shift, const float *dy,
                         const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw,
                         void *stream);
-/* the same with dy given as the bf_* fold of urn_gconv_args: dy rows = gamma * invstd * (g - c0 - xhat * c1) computed while
- * the rows are staged (g = masked gradient rows, bf_t = the BatchNorm's input; both (n_out, cout) dense); the x rows are
- * used as relu(x * xf_scale + xf_shift) (required: the fold only occurs behind a folded BatchNorm+ReLU) */
-int urn_gconv_bwd_dw_fold(const float *x, const float *xf_scale, const float *xf_shift, const float *g, const float *bf_t,
-                          const double *bf_sums, int bf_slots, int64_t bf_n, const float *bf_gamma, const float *bf_mean,
-                          const float *bf_invstd, const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout,
-                          float *dw, void *stream);
 /* the same with a row stride ld_dy >= cout of dy (dy is a column block of a wider matrix) */
 int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy,
                              const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw,

@@ -428,80 +428,3 @@ def test_pairs_strip_variant(dev, cin, cout):
                 assert rel(y_a.cpu().numpy(), y_loop.cpu().numpy()) < 1e-6, (cin, cout, split, xf)
     finally:
         L.urn_set_option(b'pairs_split', 0); L.urn_set_option(b'pairs_v3', 0x17E); L.urn_set_option(b'pairs_max_cin', 80)
-
-
-@pytest.mark.parametrize('cin,cout', [(16, 16), (32, 32), (48, 48), (80, 80), (32, 64), (64, 32), (96, 48)])
-def test_bn_backward_apply_folded_into_the_gathers(dev, cin, cout):
-    """urn_gconv_args.bf_* / urn_gconv_bwd_dw_fold: the BatchNorm-backward apply pass folded into its consumers.  `cin` =
-    channels of the BatchNorm (the gathered operand of the input gradient, the dy operand of the weight gradient).  Against
-    the materialised route -- urn_bn_bwd_apply_sums writes the rows, the same kernels read them -- within 1e-6 (another
-    rounding of the same expression: two FMAs on coefficients formed in fp64 instead of the apply kernel's five
-    operations), the BatchNorm's parameter gradients bit-equal, and within 1e-5 of an fp64 evaluation."""
-    from uresnet_pytorch_amd import lib as _l, sparse_ops as so
-    L = _l.load()
-    S, SLOTS = 32, 8
-    c, f = cloud(23, S, 2500, 2)
-    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
-    n = geo.n[0]
-    assert L.urn_gconv_bn_fold_ok(cin, cout, 27, 64, 0) == 1
-    gen = torch.Generator(device='cpu').manual_seed(cin * 11 + cout)
-    t = torch.randn(n, cin, generator=gen).to(dev)                       # the BatchNorm's input
-    g = (torch.randn(n, cin, generator=gen) * (torch.rand(n, cin, generator=gen) > 0.4)).to(dev)   # masked gradient of its output
-    gamma = (torch.rand(cin, generator=gen) + 0.5).to(dev)
-    mean = t.mean(0); invstd = 1.0 / torch.sqrt(t.var(0, unbiased=False) + 1e-4)
-    xh = (t.double() - mean.double()) * invstd.double()
-    sums = torch.zeros(SLOTS, 2, cin, dtype=torch.float64, device=dev)
-    sums[3, 0] = g.double().sum(0); sums[5, 1] = (g.double() * xh).sum(0)   # (spread over slots: the kernels add all of them)
-    wt = (torch.randn(27, cout, cin, generator=gen) * 0.1).to(dev)        # (K, produced channels, gathered channels) operand of the gather conv
-    wf = torch.empty_like(wt)
-    _l.check(L.urn_weight_fragments(wt.data_ptr(), 27, cout, cin, wf.data_ptr(), _l.stream()))
-    pl = geo.pairs['nbr'][0]
-    # materialised route
-    dg0 = torch.zeros(cin, device=dev); db0 = torch.zeros(cin, device=dev); d_t = torch.empty(n, cin, device=dev)
-    _l.check(L.urn_bn_bwd_apply_sums(t.data_ptr(), g.data_ptr(), None, 0, n, cin, gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                     sums.data_ptr(), SLOTS, dg0.data_ptr(), db0.data_ptr(), d_t.data_ptr(), _l.stream()))
-
-    def conv(xrows, fold):
-        y = torch.empty(n, cout, device=dev)
-        a = _l.GConvArgs()
-        a.x = xrows.data_ptr(); a.wt = wt.data_ptr(); a.wt_frag = wf.data_ptr(); a.tbl = geo.nbr[0].data_ptr(); a.ld = geo.ld; a.K = 27
-        a.flip = 1; a.n_out = n; a.cin = cin; a.cout = cout; a.y = y.data_ptr(); a.pairs = pl[0].data_ptr(); a.pairs_tile = pl[1]
-        dg = torch.zeros(cin, device=dev); db = torch.zeros(cin, device=dev)
-        if fold:
-            a.bf_t = t.data_ptr(); a.bf_sums = sums.data_ptr(); a.bf_slots = SLOTS; a.bf_n = n; a.bf_gamma = gamma.data_ptr()
-            a.bf_mean = mean.data_ptr(); a.bf_invstd = invstd.data_ptr(); a.bf_dgamma = dg.data_ptr(); a.bf_dbeta = db.data_ptr()
-        _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
-        return y, dg, db
-    y_mat, _, _ = conv(d_t, False)
-    y_fold, dg1, db1 = conv(g, True)
-    y_fold2, _, _ = conv(g, True)
-    assert torch.equal(y_fold, y_fold2)
-    assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
-    assert rel(y_fold.cpu().numpy(), y_mat.cpu().numpy()) < 1e-6
-    # fp64 evaluation of the whole expression
-    c0 = sums[:, 0].sum(0) / n; c1 = sums[:, 1].sum(0) / n
-    d64 = (gamma.double() * invstd.double()) * (g.double() - c0 - xh * c1)
-    assert rel(d_t.cpu().numpy(), d64.cpu().numpy()) < 1e-6
-    nbr = geo.nbr[0][:, :n].cpu().numpy()
-    dd, wd = d64.cpu().numpy(), wt.double().cpu().numpy()
-    ref = np.zeros((n, cout))
-    for k in range(27):
-        m = nbr[26 - k] >= 0                       # flip = 1: table row 26 - k carries offset k's weights
-        ref[m] += dd[nbr[26 - k][m]] @ wd[k].T
-    assert rel(y_fold.cpu().numpy(), ref) < TOL, rel(y_fold.cpu().numpy(), ref)
-    # weight gradient: dy = the folded rows (cin channels here), x = relu(x0 * sc + sh) with cout channels
-    x0 = torch.randn(n, cout, generator=gen).to(dev)
-    sc = (torch.rand(cout, generator=gen) + 0.5).to(dev); sh = (torch.randn(cout, generator=gen) * 0.1).to(dev)
-    dw_mat = torch.zeros(27, cout, cin, device=dev); dw_fold = torch.zeros(27, cout, cin, device=dev)
-    _l.check(L.urn_gconv_bwd_dw_ex(x0.data_ptr(), sc.data_ptr(), sh.data_ptr(), d_t.data_ptr(), geo.nbr[0].data_ptr(), geo.ld, 27, n,
-                                   cout, cin, dw_mat.data_ptr(), _l.stream()), 'bwd_dw_ex')
-    _l.check(L.urn_gconv_bwd_dw_fold(x0.data_ptr(), sc.data_ptr(), sh.data_ptr(), g.data_ptr(), t.data_ptr(), sums.data_ptr(), SLOTS, n,
-                                     gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), geo.nbr[0].data_ptr(), geo.ld, 27, n,
-                                     cout, cin, dw_fold.data_ptr(), _l.stream()), 'bwd_dw_fold')
-    assert rel(dw_fold.cpu().numpy(), dw_mat.cpu().numpy()) < 2e-6
-    xr = torch.relu(x0.double() * sc.double() + sh.double()).cpu().numpy()
-    refw = np.zeros((27, cout, cin))
-    for k in range(27):
-        m = nbr[k] >= 0
-        refw[k] = xr[nbr[k][m]].T @ dd[m]
-    assert rel(dw_fold.cpu().numpy(), refw) < TOL

@@ -371,35 +371,6 @@ def test_executor_matches_per_layer_path(dev):
         assert rel(res['slab'][2][k], res['fused'][2][k]) < 1e-6, k
 
 
-def test_executor_apply_fold_matches_materialised_route(dev):
-    """urn_set_option("net_fold"): the BatchNorm-backward apply of every block's second BatchNorm folded into conv1's input-
-    and weight-gradient kernels (default) against the route that writes those rows with urn_bn_bwd_apply_sums: same logits
-    (the forward pass is untouched: bitwise), every parameter gradient within 2e-6 (another rounding of the apply's
-    expression; weight-gradient atomics), on a 4-level network whose levels have 16..64 channels."""
-    from uresnet_pytorch_amd import lib as _l
-    from uresnet_pytorch_amd.models import SparseSegmentationLoss
-    L = _l.load()
-    S, m, Lv, nc = 64, 16, 4, 5
-    blob = make_sparse_blob([7, 8], S, 3000)
-    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=nc)
-    P = orc.init_params(m, Lv, nc, seed=4)
-    data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
-    res = {}
-    try:
-        for fold in (1, 0):
-            L.urn_set_option(b'net_fold', fold)
-            net = make_model(flags, P, dev)
-            out = net(data)
-            loss, _ = SparseSegmentationLoss(flags)(out, [data], [label], None)
-            loss.backward()
-            res[fold] = (out[0].detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()})
-    finally:
-        L.urn_set_option(b'net_fold', 1)
-    assert np.array_equal(res[0][0], res[1][0])
-    worst = max(rel(res[1][1][k], res[0][1][k]) for k in res[0][1])
-    assert worst < 2e-6, worst
-
-
 def test_fused_conv_pieces_vs_oracle(dev):
     """urn_gconv_fwd_ex: BatchNormReLU folded into the load, column statistics epilogue, BatchNorm-backward
     reduce epilogue; urn_gconv_bwd_dw_ex with the same input transform -- each against the oracle."""

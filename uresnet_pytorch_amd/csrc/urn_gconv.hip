@@ -196,16 +196,12 @@ __global__ __launch_bounds__(256) void k_gconv_dw(const float *__restrict__ x, c
 // PREC: MFMA operand precision, 0 fp32, 1 bf16, 2 fp16 (as in the forward kernel): the staged rows are rounded while they
 //       are parked; a fragment = four consecutive PAIRS of one channel, assembled from four 16-bit LDS reads
 //       (v_mfma_f32_16x16x16: one MFMA per 16 pairs instead of four).
-// XF == 2: XF == 1 and the dy rows given as the BatchNorm-backward fold of urn_gconv_args.bf_*: dy = masked gradient rows g,
-// used as a1 * g + a2 * t + a3 while they are parked (t = the BatchNorm's input rows, coefficients derived from the
-// accumulated slab in the prologue, as in the pair-list kernel) -- the apply pass that would write those rows is gone
-struct DwFold { const float *t; const double *sums; int slots; double inv_n; const float *gamma, *mean, *invstd; };
 template <int S, int XF, int KT, int PREC = 0>
 __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, const float *__restrict__ xf_scale,
                                                    const float *__restrict__ xf_shift, const float *__restrict__ dy,
                                                    const int *__restrict__ tbl, long ld, long n_out, int cin,
                                                    int cout, long chunk, int n_ci_tiles,
-                                                   float *__restrict__ dw, long ld_dy, float *__restrict__ slab, DwFold bf)
+                                                   float *__restrict__ dw, long ld_dy, float *__restrict__ slab)
 {
     __shared__ int s_in[DW2_LIST], s_out[DW2_LIST];
     __shared__ int s_cnt[16];
@@ -267,25 +263,6 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
         b_rr[j] = e / (co_w / 4); b_c4[j] = e - b_rr[j] * (co_w / 4);
     }
     f32x4 ra[2][2], rb[2][3];   // register ring: two batches in flight
-    f32x4 rt[XF == 2 ? 2 : 1][XF == 2 ? 3 : 1];   // ... and the BatchNorm input rows beside the dy rows (fold)
-    f32x4 ba1[XF == 2 ? 3 : 1], ba2[XF == 2 ? 3 : 1], ba3[XF == 2 ? 3 : 1];
-    if constexpr (XF == 2) {
-        __shared__ float s_bf[3][DW_MAXN * 16];
-        for (int e = tid; e < co_w; e += 256) {
-            const int ch = co0 + e;
-            const float is = bf.invstd[ch], mu = bf.mean[ch], ga = bf.gamma[ch];
-            double v0, v1;
-            urn_slab_sum2(bf.sums + ch, cout, bf.slots, v0, v1);
-            const double a1 = (double)ga * (double)is;
-            const double a2 = -a1 * (double)is * (v1 * bf.inv_n);
-            s_bf[0][e] = (float)a1; s_bf[1][e] = (float)a2; s_bf[2][e] = (float)(-a1 * (v0 * bf.inv_n) - a2 * (double)mu);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            ba1[j] = *(const f32x4 *)&s_bf[0][4 * b_c4[j]]; ba2[j] = *(const f32x4 *)&s_bf[1][4 * b_c4[j]]; ba3[j] = *(const f32x4 *)&s_bf[2][4 * b_c4[j]];
-        }
-    }
 
     const long row_begin = (long)blockIdx.x * chunk;
     const long row_end = min(n_out, row_begin + chunk);
@@ -336,7 +313,6 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
             const int p = min(b * KT + b_rr[j], cnt - 1);
             rb[u][j] = *(const f32x4 *)(dy + (long)s_out[p] * ld_dy + co0 + 4 * b_c4[j]);
-            if constexpr (XF == 2) rt[u][j] = *(const f32x4 *)(bf.t + (long)s_out[p] * cout + co0 + 4 * b_c4[j]);
         };
         auto park_a = [&](int b, int buf, auto slot, auto jj) {
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
@@ -354,10 +330,6 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
             constexpr int u = decltype(slot)::value, j = decltype(jj)::value;
             const int nb = cnt - b * KT;
             f32x4 v = rb[u][j];
-            if constexpr (XF == 2) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], ba1[j][k], fmaf(rt[u][j][k], ba2[j][k], ba3[j][k]));
-            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = b_rr[j] < nb ? v[k] : 0.f;
             lds_store(&s_b[buf][b_rr[j]][0], b_c4[j], v);
@@ -564,8 +536,7 @@ static void dw2_plan(int K, int64_t n_out, int cin, int cout, int &chunks, long 
 }
 
 static int dw_launch(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy, const int32_t *tbl,
-                     int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw, float *slab, int64_t slab_bytes, void *stream,
-                     const DwFold *fold = nullptr);
+                     int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw, float *slab, int64_t slab_bytes, void *stream);
 
 extern "C" int64_t urn_gconv_dw_2stage_scratch_bytes(int K, int64_t n_out, int cin, int cout)
 {
@@ -599,21 +570,8 @@ extern "C" int urn_gconv_bwd_dw_strided(const float *x, const float *xf_scale, c
     return dw_launch(x, xf_scale, xf_shift, dy, ld_dy, tbl, ld, K, n_out, cin, cout, dw, nullptr, 0, stream);
 }
 
-extern "C" int urn_gconv_bwd_dw_fold(const float *x, const float *xf_scale, const float *xf_shift, const float *g, const float *bf_t,
-                                     const double *bf_sums, int bf_slots, int64_t bf_n, const float *bf_gamma, const float *bf_mean,
-                                     const float *bf_invstd, const int32_t *tbl, int64_t ld, int K, int64_t n_out, int cin, int cout,
-                                     float *dw, void *stream)
-{
-    URN_CHECK_ARG(xf_scale && xf_shift && bf_t && bf_sums && bf_slots > 0 && bf_n > 0 && bf_gamma && bf_mean && bf_invstd,
-                  "incomplete fold (the x rows must carry a folded BatchNorm+ReLU as well)");
-    URN_CHECK_ARG(cin % 16 == 0 && cout % 16 == 0 && g_dw_kernel == 2, "the fold needs k_gconv_dw2 (channel counts that are multiples of 16)");
-    const DwFold f{bf_t, bf_sums, bf_slots, 1.0 / (double)bf_n, bf_gamma, bf_mean, bf_invstd};
-    return dw_launch(x, xf_scale, xf_shift, g, cout, tbl, ld, K, n_out, cin, cout, dw, nullptr, 0, stream, &f);
-}
-
 static int dw_launch(const float *x, const float *xf_scale, const float *xf_shift, const float *dy, int64_t ld_dy, const int32_t *tbl,
-                     int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw, float *slab, int64_t slab_bytes, void *stream,
-                     const DwFold *fold)
+                     int64_t ld, int K, int64_t n_out, int cin, int cout, float *dw, float *slab, int64_t slab_bytes, void *stream)
 {
     URN_CHECK_ARG(ld_dy >= cout && ld_dy % 4 == 0, "ld_dy smaller than the row or not a multiple of 4");
     if (n_out <= 0) return URN_OK;
@@ -647,7 +605,6 @@ static int dw_launch(const float *x, const float *xf_scale, const float *xf_shif
     if (prof) urn_prof_begin(URN_PROF_DW, st);
     const dim3 grid(chunks, K, n_ci_tiles * n_co_tiles);
     const int prec = g_opt_precision;   // 0 fp32, 1 bf16, 2 fp16 (urn_set_option "gconv_precision")
-    const DwFold bf = fold ? *fold : DwFold{nullptr, nullptr, 0, 0.0, nullptr, nullptr, nullptr};
     if (g_dw_kernel == 2) {
         const int ci_w = cin < DW_MAXI * 16 ? cin : DW_MAXI * 16, co_w = cout < DW_MAXN * 16 ? cout : DW_MAXN * 16;
         const int nblk_max = (ci_w / 16) * (co_w / 16);   // of the widest tile
@@ -657,15 +614,14 @@ static int dw_launch(const float *x, const float *xf_scale, const float *xf_shif
 #define URN_DW2P(Sv, XFv, KTv)                                                                                                       \
         do {                                                                                                                         \
             if (prec == 1) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 1>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, \
-                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab, bf);    \
+                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab);        \
             else if (prec == 2) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 2>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, \
-                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab, bf); \
+                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab); \
             else hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 0>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
-                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab, bf);                        \
+                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab);                            \
         } while (0)
 #define URN_DW2K(Sv, KTv)                                                                                                            \
-        if (fold) URN_DW2P(Sv, 2, KTv);                                                                                              \
-        else if (xf_scale) URN_DW2P(Sv, 1, KTv);                                                                                     \
+        if (xf_scale) URN_DW2P(Sv, 1, KTv);                                                                                          \
         else URN_DW2P(Sv, 0, KTv);
 #define URN_DW2(Sv) case Sv: URN_DW2K(Sv, 32) break;
         // The split variants keep all four matrix pipes of a CU busy: faster alone (16 x 16 at 50k rows: 29 -> 24 us;

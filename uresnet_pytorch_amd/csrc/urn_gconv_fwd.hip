@@ -313,7 +313,7 @@ extern int g_dw_pairs;
 extern int g_pairs_deep, g_pairs_v3;
 extern int g_dw_2stage;
 extern long long *g_dense_stamps;
-extern int g_net_wfrag, g_net_fold;
+extern int g_net_wfrag;
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
 static long long *g_opt_stamps = nullptr;
@@ -355,7 +355,6 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "dw_pairs")) { g_dw_pairs = value != 0; return URN_OK; }
     if (!strcmp(key, "net_dbg_skip_dw")) { g_net_skip_dw = value != 0; return URN_OK; }
     if (!strcmp(key, "net_wfrag")) { g_net_wfrag = value != 0; return URN_OK; }
-    if (!strcmp(key, "net_fold")) { g_net_fold = value != 0; return URN_OK; }
     if (!strcmp(key, "dw_2stage")) { g_dw_2stage = value != 0; return URN_OK; }
     if (!strcmp(key, "dwp_cap")) { g_dwp_cap = value >= 1 && value <= 5 ? (int)value : 2; return URN_OK; }
     if (!strcmp(key, "dwp_dbg")) { g_dwp_dbg = (int)value; return URN_OK; }
@@ -488,12 +487,6 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     a.cout = u->cout; a.cin = u->cin; a.res = u->res; a.y = u->y; a.xf_scale = u->xf_scale; a.xf_shift = u->xf_shift; a.epi = u->epilogue;
     a.part = u->part; a.e_x = u->e_x; a.e_scale = u->e_scale; a.e_shift = u->e_shift; a.e_mean = u->e_mean;
     a.e_invstd = u->e_invstd; a.dbg = g_opt_dbg; a.stamps = g_opt_stamps;
-    if (u->bf_t) {
-        URN_CHECK_ARG(u->bf_sums && u->bf_slots > 0 && u->bf_n > 0 && u->bf_gamma && u->bf_mean && u->bf_invstd && u->bf_dgamma && u->bf_dbeta &&
-                      !u->xf_scale && !u->xs_sums[0], "incomplete bf_* fields (or combined with the input BatchNorm fold)");
-        a.bf_t = u->bf_t; a.bf_sums = u->bf_sums; a.bf_slots = u->bf_slots; a.bf_n = (long)u->bf_n; a.bf_gamma = u->bf_gamma;
-        a.bf_mean = u->bf_mean; a.bf_invstd = u->bf_invstd; a.bf_dgamma = u->bf_dgamma; a.bf_dbeta = u->bf_dbeta;
-    }
     a.prec = u->precision > 0 ? u->precision - 1 : g_opt_precision;   // 0 fp32, 1 bf16, 2 fp16
     a.ldx = u->ldx > 0 ? (long)u->ldx : (long)u->cin;
     a.ldy = u->ldy > 0 ? (long)u->ldy : (long)u->cout;
@@ -552,11 +545,6 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
         }
         a.pairs = nullptr; a.p_tile = 0;
     }
-    if (u->bf_t) {
-        if (prof) urn_prof_end(st);
-        urn_set_error("urn_gconv_fwd_ex: the bf_* fold needs the strip variant of the pair-list kernel (urn_gconv_bn_fold_ok; cin=%d cout=%d K=%d)", u->cin, u->cout, u->K);
-        return URN_EUNSUPPORTED;
-    }
     if (off32_ok && ((g_opt_kernel >= 6 && !in_kernel) || sums_mode || a.prec || strided)) {
         const int np6 = urn_gconv_tile_launch(a, ks, u->n_out, st);
         if (np6 > 0) {
@@ -599,15 +587,6 @@ extern "C" int urn_gconv_fwd_ex(const urn_gconv_args *u, int *n_tiles, void *str
     URN_LAUNCH_CHECK();
     if (want_fin) return finalize_launches(u, np, stream);
     return URN_OK;
-}
-
-extern "C" int urn_gconv_bn_fold_ok(int cin, int cout, int K, int tile, int precision)
-{
-    if (cin <= 0 || cout <= 0 || cin % 16 || cout % 16 || K < 8 || K > 27 || (tile != 32 && tile != 64 && tile != 128)) return 0;
-    if (precision < 0 || precision > 2 || g_opt_kernel < 7 || (precision != 0 && !g_pairs_prec)) return 0;
-    // (the executor always hands the fragment-ordered weights over: the wide-input rule of the dispatcher with wt_frag set)
-    const bool pairs_shape = K == 8 || ((cin <= g_pairs_max_cin || g_pairs_frag_wide) && cout <= g_pairs_max_cout);
-    return pairs_shape && urn_pairs_strip_ok(cin, precision) ? 1 : 0;
 }
 
 extern "C" int urn_gconv_fwd(const float *x, const float *wt, const int32_t *tbl, int64_t ld, int K, int flip,

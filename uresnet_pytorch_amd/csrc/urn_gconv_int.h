@@ -42,12 +42,6 @@ struct GArgs {
     const int *pairs;
     int p_tile, p_split, p_cw, p_deep;   // p_deep: loop variant, 0 = block loop with per-block index loads, 1 = ring (three register sets), 2 = strip (pair words of the share in LDS)
     int p_strip;   // variant 2: blocks per wave-private strip (a multiple of 16)
-    // BatchNorm-backward apply folded into the gather (urn_gconv_args.bf_*): strip variant of the pair-list kernel only
-    const float *bf_t, *bf_gamma, *bf_mean, *bf_invstd;
-    const double *bf_sums;
-    int bf_slots;
-    long bf_n;
-    float *bf_dgamma, *bf_dbeta;
     long long *stamps;   // diagnostics (urn_set_option "gconv_stamp_ptr"): 8 s_memtime values per wave of the pair-list kernel
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets
 };
@@ -59,6 +53,5 @@ static __host__ __device__ inline long urn_pairs_tpad(int K, int T) { return (ur
 static __host__ __device__ inline long urn_pairs_words(int K, int T) { return URN_PAIRS_HDR + urn_pairs_tpad(K, T) + urn_pairs_maxb(K, T) * 16; }
 // compacted rule lists (urn_gconv_pairs.hip): returns the number of partial rows (tiles), 0 = no instantiation
 int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st);
-int urn_pairs_strip_ok(int cin, int prec);
 // 2-D workgroup tile (urn_gconv_tile.hip): returns the number of partial rows, 0 = no instantiation
 int urn_gconv_tile_launch(const GArgs &a, int ks, long n_out, hipStream_t st);

@@ -187,10 +187,9 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
     const int lcol0 = cg * 16 * NC;                // first column of the wave inside the workgroup's range
     const int col0 = colw + lcol0;
     const int LDW = cw + 4;                        // +4 floats: consecutive rows start 16 B apart in the bank row
-    // LDS: [2][cin] folded affine ([3][cin] coefficients of the BatchNorm-backward fold, XF == 2) | G slabs of (T + 1) x cw |
-    //      [2][G][cw] doubles (epilogue reduction)
+    // LDS: [2][cin] folded affine | G slabs of (T + 1) x cw | [2][G][cw] doubles (epilogue reduction)
     float *s_xf = smem;
-    float *s_slab = smem + (XF == 2 ? 3 * cin : (XF ? 2 * cin : 0));
+    float *s_slab = smem + (XF ? 2 * cin : 0);
     const long slab_words = (long)(T + 1) * LDW;
     double *s_p = (double *)(s_slab + (((long)G * slab_words + 1) & ~1L));
 
@@ -258,24 +257,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
             load_idx(b0 + 2 < b1 ? b0 + 2 : b1 - 1, pv_nn, tv_nn, pl_nn);
         }
     }
-    if constexpr (XF == 2) {
-        // BatchNorm-backward apply folded into the gather (urn_gconv_args.bf_*): a gathered element g (masked gradient) with
-        // the BatchNorm's input t at the same place is used as  gamma * invstd * (g - c0 - (t - mean) * invstd * c1)
-        //   = a1 * g + a2 * t + a3,  a1 = gamma * invstd,  a2 = -a1 * invstd * c1,  a3 = -a1 * c0 - a2 * mean
-        // (c0 / c1 = column means of g and g * xhat from the accumulated slab; coefficients in fp64, rounded once)
-        const bool keep = blockIdx.x == 0 && blockIdx.y == 0;
-        const double inv_n = g.bf_n > 0 ? 1.0 / (double)g.bf_n : 0.0;
-        for (int e = tid; e < cin; e += nthreads) {
-            const float is = g.bf_invstd[e], mu = g.bf_mean[e], ga = g.bf_gamma[e];   // requested together with the slab rows
-            double v0, v1;
-            urn_slab_sum2(g.bf_sums + e, cin, g.bf_slots, v0, v1);
-            const double a1 = (double)ga * (double)is;
-            const double a2 = -a1 * (double)is * (v1 * inv_n);
-            s_xf[e] = (float)a1; s_xf[cin + e] = (float)a2; s_xf[2 * cin + e] = (float)(-a1 * (v0 * inv_n) - a2 * (double)mu);
-            if (keep) { g.bf_dbeta[e] += (float)v0; g.bf_dgamma[e] += (float)v1; }
-        }
-    }
-    if constexpr (XF == 1) {
+    if constexpr (XF != 0) {
         if (g.xs_sums[0] != nullptr) {
             // statistics of the input rows accumulated by the producers: same arithmetic as k_bn_finalize_fwd_f
             const bool keep = blockIdx.x == 0 && blockIdx.y == 0;
@@ -493,46 +475,22 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
         URN_STAMP(5);
         if (nb > 0) {
             constexpr bool W2 = KC * NC <= 4;     // second weight register set (16 KC NC bytes per lane)
-            constexpr bool XREG = (XF == 1 && KC <= 3) || (XF == 2 && KC <= 2);   // per-channel coefficients of this lane's pieces in registers
-            f32x4 xsc[XREG ? KC : 1], xsh[XREG ? KC : 1], xa3[(XREG && XF == 2) ? KC : 1];
+            constexpr bool XREG = XF != 0 && KC <= 3;
+            f32x4 xsc[XREG ? KC : 1], xsh[XREG ? KC : 1];
             if constexpr (XREG) {
 #pragma unroll
-                for (int j = 0; j < KC; ++j) {
-                    xsc[j] = *(const f32x4 *)(s_xf + 16 * j + 4 * gq); xsh[j] = *(const f32x4 *)(s_xf + cin + 16 * j + 4 * gq);
-                    if constexpr (XF == 2) xa3[j] = *(const f32x4 *)(s_xf + 2 * cin + 16 * j + 4 * gq);
-                }
+                for (int j = 0; j < KC; ++j) { xsc[j] = *(const f32x4 *)(s_xf + 16 * j + 4 * gq); xsh[j] = *(const f32x4 *)(s_xf + cin + 16 * j + 4 * gq); }
             }
-            // XF == 2: the BatchNorm's input rows t, gathered beside the gradient rows (same row index and stride)
-            const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)(XF == 2 ? g.bf_t : g.x), 0, -1, 0x00020000);
-            f32x4 t_nxt[XF == 2 ? KC : 1];
-            auto load_t = [&](int pl) {
-                if constexpr (XF == 2) {
-                    const int vo = (int)__umul24((unsigned)(pl & 0xFFFFFF), (unsigned)ldxb) + 16 * gq;
-#pragma unroll
-                    for (int j = 0; j < KC; ++j) t_nxt[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, vo + 64 * j, 0, 0));
-                }
-            };
             auto ready2 = [&](const f32x4 (&raw)[KC], wfrag_t (&dst)[KC]) {
 #pragma unroll
                 for (int j = 0; j < KC; ++j) {
                     f32x4 v = raw[j];
-                    if constexpr (XF == 1) {
+                    if constexpr (XF != 0) {
                         f32x4 sc, sh;
                         if constexpr (XREG) { sc = xsc[j]; sh = xsh[j]; }
                         else { sc = *(const f32x4 *)(s_xf + 16 * j + 4 * gq); sh = *(const f32x4 *)(s_xf + cin + 16 * j + 4 * gq); }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
-                    }
-                    if constexpr (XF == 2) {
-                        f32x4 a1, a2, a3;
-                        if constexpr (XREG) { a1 = xsc[j]; a2 = xsh[j]; a3 = xa3[j]; }
-                        else {
-                            a1 = *(const f32x4 *)(s_xf + 16 * j + 4 * gq); a2 = *(const f32x4 *)(s_xf + cin + 16 * j + 4 * gq);
-                            a3 = *(const f32x4 *)(s_xf + 2 * cin + 16 * j + 4 * gq);
-                        }
-                        const f32x4 tv = t_nxt[j];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], a1[k], fmaf(tv[k], a2[k], a3[k]));
                     }
                     if constexpr (PREC == 0) {
 #pragma unroll
@@ -553,7 +511,6 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
             int t_c = __builtin_amdgcn_readfirstlane(strip_t[0]);
             load_w(w_cur, t_c, 0);
             load_a(a_nxt, strip[gp], 0);
-            load_t(strip[gp]);
             int pv_c2 = strip[r];
             const int i1 = nb > 1 ? 1 : 0;
             int pv_n2 = strip[i1 * 16 + r], pl_n2 = strip[i1 * 16 + gp];
@@ -569,7 +526,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
                 const bool more = i + 1 < nb;                 // wave-uniform
                 const bool chg = more && t_n != t_c;
                 if constexpr (W2) { if (chg) load_w(w_nxt, t_n, 0); }
-                if (more) { load_a(a_nxt, pl_n2, 0); load_t(pl_n2); }
+                if (more) load_a(a_nxt, pl_n2, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (PREC == 0) {
 #pragma unroll
@@ -760,8 +717,7 @@ static void launch_pairs16(const GArgs &a, dim3 grid, dim3 block, size_t lds, hi
     const bool xf = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
     if constexpr (NC <= 2) {
         if (a.p_deep == 2) {
-            if (a.bf_t) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 2, 2, PREC>), grid, block, lds, st, a);
-            else if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 2, PREC>), grid, block, lds, st, a);
+            if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 2, PREC>), grid, block, lds, st, a);
             else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 2, PREC>), grid, block, lds, st, a);
             return;
         }
@@ -814,8 +770,7 @@ static void launch_pairs2(const GArgs &a, dim3 grid, dim3 block, size_t lds, hip
 {
     const bool xf = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
     if (a.p_deep == 2) {
-        if (a.bf_t) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 2, 2>), grid, block, lds, st, a);
-        else if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 2>), grid, block, lds, st, a);
+        if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 2>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 2>), grid, block, lds, st, a);
         return;
     }
@@ -831,24 +786,6 @@ static void launch_pairs2(const GArgs &a, dim3 grid, dim3 block, size_t lds, hip
     else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 0>), grid, block, lds, st, a);
 }
 
-extern int g_pairs_v3;
-// the contraction chunk of a shape: 16 KC channels per step, KC the largest of 8, 6, 5, 4, 3, 2 that divides cin / 16 (else 1)
-static int pairs_kc(int cin)
-{
-    const int ks = cin / 16;
-    for (int d : {8, 6, 5, 4, 3, 2})
-        if (ks % d == 0) return d;
-    return 1;
-}
-
-// does a call with this many gathered channels run on the strip variant (the one that implements the bf_* fold)?
-int urn_pairs_strip_ok(int cin, int prec)
-{
-    if (cin <= 0 || cin % 16) return 0;
-    const int kc = pairs_kc(cin);
-    return ((g_pairs_v3 >> kc) & 1) && cin == 16 * kc && (prec != 0 || kc <= 6);
-}
-
 // returns the number of partial rows (tiles), 0 when the shape has no instantiation
 int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
 {
@@ -857,8 +794,10 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     if (a.prec != 0 && (a.wfrag == nullptr || a.wfrag_prec != a.prec)) return 0;   // the 16-bit variants read 16-bit fragments only
     if (a.prec == 0 && a.wfrag_prec != 0) a.wfrag = nullptr;                        // 16-bit fragments are of no use to the fp32 variants: rows of wt
     if (a.ldy % 4 || ((uintptr_t)a.y & 15) || (a.res && ((uintptr_t)a.res & 15)) || (a.e_x && ((uintptr_t)a.e_x & 15))) return 0;   // 16-byte epilogue accesses
-    const int nblk = a.cout / 16;
-    const int kc = pairs_kc(a.cin);
+    const int ks = a.cin / 16, nblk = a.cout / 16;
+    int kc = 1;
+    for (int d : {8, 6, 5, 4, 3, 2})
+        if (ks % d == 0) { kc = d; break; }
     const long ntiles = (n_out + T - 1) / T;
     if ((double)ntiles * (double)urn_pairs_words(a.K, T) * 4.0 >= 2147483648.0) return 0;   // 32-bit offsets into the lists (rows / weights: the dispatcher's off32_ok)
     // two column blocks per wave halve the gathers (every wave of a tile gathers the same rows) when the launch still has
@@ -871,7 +810,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     // g_pairs_wgs16 workgroups
     if (a.prec != 0) {
         nc = nblk % 2 == 0 ? 2 : 1;
-        if (nblk % 4 == 0 && ntiles * (nblk / 4) >= g_pairs_wgs16 && a.bf_t == nullptr) nc = 4;   // (the fold lives in the strip variant: one or two column blocks)
+        if (nblk % 4 == 0 && ntiles * (nblk / 4) >= g_pairs_wgs16) nc = 4;
     }
     if (g_pairs_nc == 1 || (g_pairs_nc == 2 && nblk % 2 == 0 && (kc <= 6 || a.prec != 0)) || (g_pairs_nc == 4 && nblk % 4 == 0 && a.prec != 0)) nc = g_pairs_nc;
     const int cbg_all = nblk / nc;
@@ -890,7 +829,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     const int maxb = (int)urn_pairs_maxb(a.K, T);
     auto strip_blocks = [&](int G) { return (((maxb + G - 1) / G + 1) + 15) & ~15; };   // longest share of a tile's block list, rounded up to whole 16-block fills
     auto lds_bytes = [&](int G) {
-        size_t w = (size_t)3 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
+        size_t w = (size_t)2 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
         return w * 4 + (size_t)2 * G * cw * 8 + (deep ? (size_t)cbg * G * URN_PAIRS_IDXB * 17 * 4 : 0) +
                (strip ? (size_t)cbg * G * strip_blocks(G) * 17 * 4 + 16 : 0);
     };
@@ -908,7 +847,6 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     }
     if (lds_bytes(G) > 65536) return 0;
     a.p_split = G; a.p_cw = cw; a.p_deep = strip ? 2 : (deep ? 1 : 0); a.p_strip = strip ? strip_blocks(G) : 0;
-    if (a.bf_t != nullptr && !strip) return 0;   // the BatchNorm-backward fold exists in the strip variant only (callers ask urn_gconv_bn_fold_ok first)
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
     const size_t lds = lds_bytes(G);
 #define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs2<KCv, NCv>(a, grid, block, lds, st); return (int)ntiles; }

@@ -24,7 +24,6 @@ int g_net_skip_dw = 0;     // timing only (urn_set_option "net_dbg_skip_dw"): no
 int g_dw_pairs = 0;        // weight gradients on the two-stage pair-list kernel (bitwise reproducible) instead of the atomics kernel (urn_set_option "dw_pairs")
 int g_net_side_probe = 4;   // candidate side streams tried by an executor's first backward (urn_set_option "net_side_probe"; 0/1 = keep the first)
 int g_net_side_verbose = 0;
-int g_net_fold = 1;         // BatchNorm-backward apply of a block's second BatchNorm folded into the gathers of conv1's input and weight gradients (urn_set_option "net_fold"): 18 of the 44 apply launches of a cfg3 step gone
 
 namespace {
 
@@ -541,10 +540,7 @@ struct urn_net {
     // Weight gradients go to the side stream behind a fork (event record on the main stream, wait on the side stream).
     // They can be queued and forked in groups (g_dw_group > 1) -- measured slower: the later a weight gradient
     // starts, the less of it overlaps with the dX chain -- so the default is one fork per convolution.
-    // A BatchNorm-backward apply that is not run: its output rows exist only as (g, t, accumulated sums) and are formed
-    // where they are consumed (urn_gconv_args.bf_*, urn_gconv_bwd_dw_fold)
-    struct Fold { const float *g = nullptr, *t = nullptr; const double *sums = nullptr; const BNP *bn = nullptr; int64_t n = 0; };
-    struct DwJob { ConvP *c; const BNP *xf; const float *dy; const int32_t *tbl_f; int64_t n_out; int64_t ld_dy; void *scratch; Fold fold; };
+    struct DwJob { ConvP *c; const BNP *xf; const float *dy; const int32_t *tbl_f; int64_t n_out; int64_t ld_dy; void *scratch; };
     std::vector<DwJob> dw_queue;
     void dw_flush()
     {
@@ -557,61 +553,29 @@ struct urn_net {
                 side_used = true;
             }
         }
-        for (const DwJob &j : dw_queue) {
-            if (j.fold.g && !g_net_skip_dw) {
-                const BNP &fb = *j.fold.bn;
-                check(urn_gconv_bwd_dw_fold(j.c->x, j.xf->scale, j.xf->shift, j.fold.g, j.fold.t, j.fold.sums, SUM_SLOTS, j.fold.n,
-                                            params + fb.w, fb.mean, fb.invstd, j.tbl_f, geo.ld, j.c->K, j.n_out, j.c->cin, j.c->cout,
-                                            grads + j.c->w, ws));
-                continue;
-            }
-            check(dw_call(*j.c, j.xf, j.dy, j.ld_dy, j.tbl_f, j.n_out, ws, j.scratch));
-        }
+        for (const DwJob &j : dw_queue) check(dw_call(*j.c, j.xf, j.dy, j.ld_dy, j.tbl_f, j.n_out, ws, j.scratch));
         dw_queue.clear();
     }
-    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out, int64_t ld_dy, void *scratch,
-                   const Fold *fold = nullptr)
+    void dw_launch(ConvP &c, const BNP *xf, const float *dy, const int32_t *tbl_f, int64_t n_out, int64_t ld_dy, void *scratch)
     {
-        dw_queue.push_back(DwJob{&c, xf, dy, tbl_f, n_out, ld_dy, scratch, fold ? *fold : Fold()});
+        dw_queue.push_back(DwJob{&c, xf, dy, tbl_f, n_out, ld_dy, scratch});
         if ((int)dw_queue.size() >= g_dw_group) dw_flush();
-    }
-    // can the apply of the BatchNorm in front of conv `c` (its dy side) be folded into c's two gradient kernels?
-    bool fold_ok(const ConvP &c, const int32_t *tbl_b) const
-    {
-        if (!g_net_fold || !sums_mode() || g_dw_pairs || g_dw_2stage || c.cin % 16 || c.cout % 16) return false;
-        const int32_t *list; int tile;
-        geo.pairs_of(tbl_b, list, tile);
-        if (arena.dry) { tile = 64; }   // (workspace sizing: the lists arrive with the real forward; the answer does not change the carve-outs)
-        else if (!list) return false;
-        if (!g_net_wfrag) return false;
-        return urn_gconv_bn_fold_ok(c.cout, c.cin, c.K, tile ? tile : 64, wf_prec) != 0;   // the input gradient gathers cout channels
     }
     // backward of conv(BNReLU_b(x)): returns d/dx (raw input of the BatchNorm), adds `extra` when given
     // ld_dy / ld_extra: dy / extra are column blocks of a wider matrix (the halves of a concat's gradient); 0 = dense
-    // fold_in: dy is not materialised -- it is the fold of an earlier call that was made with fold_out (the rows of `dy` are
-    // then that call's masked gradient g).  fold_out: do not run this BatchNorm's apply; hand (g, x, sums) to the consumer
-    // and return g.  (`extra` cannot be combined with fold_out.)
     float *conv_b_fused(ConvP &c, BNP &b, const float *dy, const int32_t *tbl_f, const int32_t *tbl_b, int flip_b,
-                        int64_t n_out, int64_t n_in, const float *extra, int64_t ld_dy = 0, int64_t ld_extra = 0,
-                        const Fold *fold_in = nullptr, Fold *fold_out = nullptr)
+                        int64_t n_out, int64_t n_in, const float *extra, int64_t ld_dy = 0, int64_t ld_extra = 0)
     {
         float *g = arena.f32(n_in * c.cin);
         const bool acc = sums_mode();
         double *part = acc ? sums_alloc(c.cin) : (double *)arena.alloc_bytes((size_t)urn_gconv_part_bytes(n_in, c.cin));
         float *coef = acc ? nullptr : arena.f32(2 * (int64_t)c.cin);
-        float *dx = arena.f32(n_in * c.cin);   // (carved also when the apply is folded away: the workspace model does not depend on the fold decision)
+        float *dx = arena.f32(n_in * c.cin);
         void *scratch = dw_scratch(c, tbl_f, n_out);
-        if (fold_out) { fold_out->g = g; fold_out->t = b.x; fold_out->sums = part; fold_out->bn = &b; fold_out->n = n_in; }
         if (live()) {
-            dw_launch(c, &b, dy, tbl_f, n_out, ld_dy, scratch, fold_in);
+            dw_launch(c, &b, dy, tbl_f, n_out, ld_dy, scratch);
             urn_gconv_args a;
             memset(&a, 0, sizeof(a));
-            if (fold_in) {
-                const BNP &fb = *fold_in->bn;
-                a.bf_t = fold_in->t; a.bf_sums = fold_in->sums; a.bf_slots = SUM_SLOTS; a.bf_n = fold_in->n;
-                a.bf_gamma = params + fb.w; a.bf_mean = fb.mean; a.bf_invstd = fb.invstd;
-                a.bf_dgamma = grads + fb.w; a.bf_dbeta = grads + fb.b;
-            }
             a.x = dy; a.wt = params + c.w; a.wt_frag = frag_of(a.wt, c.cout, c.cin); a.wt_frag_prec = wf_prec; a.tbl = tbl_b; a.ld = geo.ld; a.K = c.K; a.flip = flip_b; a.n_out = n_in;
             a.cin = c.cout; a.cout = c.cin; a.y = g; a.ldx = ld_dy;
             geo.pairs_of(tbl_b, a.pairs, a.pairs_tile);
@@ -621,9 +585,8 @@ struct urn_net {
             if (acc) {
                 a.part_slots = SUM_SLOTS;
                 check(urn_gconv_fwd_ex(&a, &n_part, st));
-                if (!fold_out)
-                    check(urn_bn_bwd_apply_sums(b.x, g, extra, ld_extra, n_in, c.cin, params + b.w, b.mean, b.invstd, part, SUM_SLOTS,
-                                                grads + b.w, grads + b.b, dx, st));
+                check(urn_bn_bwd_apply_sums(b.x, g, extra, ld_extra, n_in, c.cin, params + b.w, b.mean, b.invstd, part, SUM_SLOTS,
+                                            grads + b.w, grads + b.b, dx, st));
             } else {
                 a.sync_word = sync_word; a.fin_n = n_in;
                 a.fin_dgamma = grads + b.w; a.fin_dbeta = grads + b.b; a.fin_coef0 = coef; a.fin_coef1 = coef + c.cin;
@@ -631,7 +594,7 @@ struct urn_net {
                 check(urn_bn_bwd_apply(b.x, g, extra, n_in, c.cin, params + b.w, b.mean, b.invstd, coef, coef + c.cin, dx, st));
             }
         }
-        return fold_out ? g : dx;
+        return dx;
     }
     // eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (and mean / invstd for the
     // last BatchNormReLU) of EVERY BatchNorm, one launch; the convolutions then fold them like the batch statistics
@@ -709,11 +672,8 @@ struct urn_net {
         const int32_t *nbr = geo.nbr[l];
         const float *dsc = dy;
         if (k.has_nin) dsc = conv_bwd(k.nin, dy, nbr + 13 * geo.ld, nbr + 13 * geo.ld, 0, n, n, true);
-        // the apply of bn2 (gradient of conv1's output) is folded into conv1's two gradient kernels where they have the fold
-        Fold f;
-        const bool fold = fold_ok(k.conv1, nbr);
-        float *d = conv_b_fused(k.conv2, k.bn2, dy, nbr, nbr, 1, n, n, nullptr, 0, 0, nullptr, fold ? &f : nullptr);
-        return conv_b_fused(k.conv1, k.bn1, d, nbr, nbr, 1, n, n, dsc, 0, 0, fold ? &f : nullptr);   // + gradient of the shortcut branch
+        float *d = conv_b_fused(k.conv2, k.bn2, dy, nbr, nbr, 1, n, n, nullptr);
+        return conv_b_fused(k.conv1, k.bn1, d, nbr, nbr, 1, n, n, dsc);   // + gradient of the shortcut branch
     }
     float *u_b(ULevel &lv, float *dy, int l)
     {

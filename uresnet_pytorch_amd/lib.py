@@ -36,10 +36,7 @@ class GConvArgs(ctypes.Structure):
                 ('xs_invstd', ctypes.c_void_p), ('xs_scale', ctypes.c_void_p), ('xs_shift', ctypes.c_void_p),
                 ('xs_running_mean', ctypes.c_void_p), ('xs_running_var', ctypes.c_void_p), ('precision', ctypes.c_int),
                 ('ldx', ctypes.c_int64), ('ldy', ctypes.c_int64), ('pairs', ctypes.c_void_p), ('pairs_tile', ctypes.c_int),
-                ('wt_frag', ctypes.c_void_p), ('wt_frag_prec', ctypes.c_int),
-                ('bf_t', ctypes.c_void_p), ('bf_sums', ctypes.c_void_p), ('bf_slots', ctypes.c_int), ('bf_n', ctypes.c_int64),
-                ('bf_gamma', ctypes.c_void_p), ('bf_mean', ctypes.c_void_p), ('bf_invstd', ctypes.c_void_p),
-                ('bf_dgamma', ctypes.c_void_p), ('bf_dbeta', ctypes.c_void_p)]
+                ('wt_frag', ctypes.c_void_p), ('wt_frag_prec', ctypes.c_int)]
 
 
 class DenseGeom(ctypes.Structure):
@@ -105,9 +102,6 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     'urn_bn_bwd_apply_sums': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'urn_gconv_bn_fold_ok': (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    'urn_gconv_bwd_dw_fold': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p, c_void_p]),
     'urn_gconv_bwd_dw_strided': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_i64,
                                          c_int, c_int, c_void_p, c_void_p]),
     'urn_gconv_dw_2stage_scratch_bytes': (c_i64, [c_int, c_i64, c_int, c_int]),
