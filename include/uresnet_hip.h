@@ -437,6 +437,23 @@ int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const int64_t *n, 
                     const float *params, float *running, const float *site_feats, void *ws, int64_t ws_bytes,
                     float *out_rows, int training, void *stream);
 int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stream);
+/* Optional, before a forward: the Linear head (reference uresnet_sparse.py:25,36; W (num_class, m) row-major, b (num_class))
+ * run INSIDE the executor for the NEXT urn_net_forward and its backward: the last BatchNormReLU, the OutputLayer and the
+ * Linear are one kernel (urn_tail_fwd), their gradients one kernel + the BatchNorm's apply (urn_tail_bwd).  out_rows of
+ * that forward is then the (n_rows, num_class) LOGITS, d_rows of its backward their gradient, and the head's parameter
+ * gradients are accumulated at grads[urn_net_param_count ..] (W, then b).  Fused path with accumulated statistics only
+ * (flags 0), m <= 32; otherwise URN_EUNSUPPORTED and nothing is armed. */
+int urn_net_set_head(urn_net *net, const float *W, const float *b);
+/* the two kernels of the tail, for direct use (see urn_net_set_head): sums = accumulated statistics slab of x
+ * ([slots][2][m] doubles) from which scale / shift (and mean / invstd / running statistics) are derived, or NULL = scale /
+ * shift given; part = the slab the BatchNorm-backward sums are accumulated into (zeroed by the caller) */
+int urn_tail_fwd(const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W, const float *b,
+                 const double *sums, int slots, int64_t n_sites, double eps, const float *gamma, const float *beta,
+                 float *mean, float *invstd, float *scale, float *shift, float *running_mean, float *running_var,
+                 double momentum, float *logits, void *stream);
+int urn_tail_bwd(const float *dlogits, const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W,
+                 const float *scale, const float *shift, const float *mean, const float *invstd, float *gsite,
+                 float *dW, float *db, double *part, int slots, void *stream);
 /* Side-stream probe: the ONE call of the executor that synchronises (`stream` and its candidate streams), therefore
  * explicit and optional -- once per handle at initialisation.  Keeps the fastest of a few candidate side streams for the
  * fork/join pattern of the backward pass against `stream` (see urn_net.hip: hardware-queue aliasing). */

@@ -371,6 +371,82 @@ def test_executor_matches_per_layer_path(dev):
         assert rel(res['slab'][2][k], res['fused'][2][k]) < 1e-6, k
 
 
+def test_tail_kernels_and_fused_head(dev):
+    """urn_tail_fwd / urn_tail_bwd (last BatchNormReLU + OutputLayer + Linear as one kernel each way) against torch in fp64 on
+    rows that share sites, and the model with the head inside the executor (urn_net_set_head, default) against the route with
+    separate OutputLayer / Linear launches: logits within 1e-6, every parameter gradient within 2e-6."""
+    import ctypes
+    from uresnet_pytorch_amd import lib as _l
+    from uresnet_pytorch_amd.models import SparseSegmentationLoss
+    L = _l.load()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    n0, N, m, nc, SLOTS = 3000, 3500, 16, 5, 8
+    x = torch.randn(n0, m, generator=g).to(dev)
+    r2s = torch.cat([torch.randperm(n0, generator=g), torch.randint(0, n0, (N - n0,), generator=g)]).to(torch.int32).to(dev)   # 500 rows share sites
+    W = (torch.randn(nc, m, generator=g) * 0.3).to(dev); b = torch.randn(nc, generator=g).to(dev)
+    gamma = (torch.rand(m, generator=g) + 0.5).to(dev); beta = (torch.randn(m, generator=g) * 0.2).to(dev)
+    sums = torch.zeros(SLOTS, 2, m, dtype=torch.float64, device=dev)
+    sums[1, 0] = x.double().sum(0); sums[6, 1] = (x.double() ** 2).sum(0)
+    mean, invstd, scale, shift = [torch.empty(m, device=dev) for _ in range(4)]
+    rm = torch.zeros(m, device=dev); rv = torch.ones(m, device=dev)
+    logits = torch.empty(N, nc, device=dev)
+    _l.check(L.urn_tail_fwd(x.data_ptr(), r2s.data_ptr(), N, m, nc, W.data_ptr(), b.data_ptr(), sums.data_ptr(), SLOTS, n0, 1e-4,
+                            gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                            rm.data_ptr(), rv.data_ptr(), 0.9, logits.data_ptr(), _l.stream()), 'tail_fwd')
+    xd = x.double()
+    mu = xd.mean(0); var = xd.var(0, unbiased=False); isd = 1.0 / torch.sqrt(var + 1e-4)
+    y = torch.relu((xd - mu) * isd * gamma.double() + beta.double())
+    ref = y[r2s.long()] @ W.double().T + b.double()
+    assert rel(logits.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    assert rel(mean.cpu().numpy(), mu.cpu().numpy()) < 1e-6 and rel(invstd.cpu().numpy(), isd.cpu().numpy()) < 1e-6
+    assert rel(rm.cpu().numpy(), (0.1 * mu).cpu().numpy()) < 1e-6 and rel(rv.cpu().numpy(), (0.9 + 0.1 * var).cpu().numpy()) < 1e-6
+    dl = torch.randn(N, nc, generator=g).to(dev)
+    gsite = torch.zeros(n0, m, device=dev); dW = torch.zeros(nc, m, device=dev); db = torch.zeros(nc, device=dev)
+    part = torch.zeros(SLOTS, 2, m, dtype=torch.float64, device=dev)
+    _l.check(L.urn_tail_bwd(dl.data_ptr(), x.data_ptr(), r2s.data_ptr(), N, m, nc, W.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                            mean.data_ptr(), invstd.data_ptr(), gsite.data_ptr(), dW.data_ptr(), db.data_ptr(), part.data_ptr(), SLOTS,
+                            _l.stream()), 'tail_bwd')
+    mask = ((x * scale + shift) > 0).double()
+    g_rows = (dl.double() @ W.double()) * mask[r2s.long()]
+    g_ref = torch.zeros(n0, m, dtype=torch.float64, device=dev).index_add_(0, r2s.long(), g_rows)
+    assert rel(gsite.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
+    y32 = torch.relu(x * scale + shift).double()
+    assert rel(dW.cpu().numpy(), (dl.double().T @ y32[r2s.long()]).cpu().numpy()) < 1e-5
+    assert rel(db.cpu().numpy(), dl.double().sum(0).cpu().numpy()) < 1e-5
+    xh = (xd - mean.double()) * invstd.double()
+    s = part.sum(0)
+    assert rel(s[0].cpu().numpy(), g_ref.sum(0).cpu().numpy()) < 1e-6 and rel(s[1].cpu().numpy(), (g_ref * xh).sum(0).cpu().numpy()) < 1e-6
+    # the model with and without the head inside the executor
+    S, mm, Lv = 64, 16, 3
+    blob = make_sparse_blob([11, 12], S, 2500)
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=mm, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=nc)
+    P = orc.init_params(mm, Lv, nc, seed=6)
+    data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
+    data = torch.cat([data, data[:300]])            # duplicated rows: several input rows per site (InputLayer mode 3)
+    label = torch.cat([label, label[:300]])
+    res = {}
+    for fuse in (True, False):
+        net = make_model(flags, P, dev)
+        net.fuse_head = fuse
+        out = net(data)
+        loss, _ = SparseSegmentationLoss(flags)(out, [data], [label], None)
+        loss.backward()
+        res[fuse] = (out[0].detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()},
+                     {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items() if 'running' in k})
+    assert rel(res[True][0], res[False][0]) < 1e-6
+    for k in res[False][1]:
+        assert rel(res[True][1][k], res[False][1][k]) < 2e-6, k
+    for k in res[False][2]:
+        assert rel(res[True][2][k], res[False][2][k]) < 1e-6, k
+    # inference without gradients (running statistics) takes the fused tail as well
+    net = make_model(flags, P, dev).eval()
+    with torch.no_grad():
+        a = net(data)[0]
+        net.fuse_head = False
+        bb = net(data)[0]
+    assert rel(a.cpu().numpy(), bb.cpu().numpy()) < 1e-6
+
+
 def test_fused_conv_pieces_vs_oracle(dev):
     """urn_gconv_fwd_ex: BatchNormReLU folded into the load, column statistics epilogue, BatchNorm-backward
     reduce epilogue; urn_gconv_bwd_dw_ex with the same input transform -- each against the oracle."""

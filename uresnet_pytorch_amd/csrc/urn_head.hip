@@ -144,6 +144,178 @@ extern "C" int urn_head_bwd(const float *dlogits, const float *x, const int32_t 
     return URN_OK;
 }
 
+// ---- the network's tail as two kernels (executor, urn_net_set_head) ---------------------------------------------
+// Forward: last BatchNormReLU (its statistics finalized here from the accumulated slab of the producing convolution, or
+// given) + OutputLayer (site -> input row) + Linear in ONE pass: logits[i,:] = relu(x[row2site[i],:] * scale + shift) @ W^T + b.
+// The normalised (n0, m) tensor and the (N, m) row matrix are never written (four launches and two passes less).
+#define TAIL_MAXM 64
+__global__ __launch_bounds__(256) void k_tail_fwd(const float *__restrict__ x, const int *__restrict__ row2site, long n, int m, int nc,
+                                                  const float *__restrict__ W, const float *__restrict__ b,
+                                                  const double *__restrict__ sums, int slots, long n_sites, double eps,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  float *mean, float *invstd, float *scale, float *shift, float *rm, float *rv,
+                                                  double momentum, float *__restrict__ logits)
+{
+    __shared__ float s_w[HEAD_MAXC * HEAD_MAXM / 8];
+    __shared__ float s_b[HEAD_MAXC];
+    __shared__ __attribute__((aligned(16))) float s_sc[TAIL_MAXM], s_sh[TAIL_MAXM];
+    for (int e = threadIdx.x; e < nc * m; e += 256) s_w[e] = W[e];
+    if (threadIdx.x < nc) s_b[threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+    if (threadIdx.x < m) {
+        const int e = threadIdx.x;
+        if (sums) {   // same arithmetic as k_bn_finalize_fwd_f / the folding convolutions' prologue
+            const double inv_n = n_sites > 0 ? 1.0 / (double)n_sites : 0.0;
+            const float gam = gamma[e], bet = beta[e];
+            double v0, v1;
+            urn_slab_sum2(sums + e, m, slots, v0, v1);
+            const double mu = v0 * inv_n;
+            double var = v1 * inv_n - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const double is = rsqrt(var + eps);
+            const float sc = gam * (float)is;
+            const float sh = fmaf(-(float)mu, sc, bet);
+            s_sc[e] = sc; s_sh[e] = sh;
+            if (blockIdx.x == 0) {
+                mean[e] = (float)mu; invstd[e] = (float)is; scale[e] = sc; shift[e] = sh;
+                if (rm) rm[e] = (float)(momentum * rm[e] + (1.0 - momentum) * mu);
+                if (rv) rv[e] = (float)(momentum * rv[e] + (1.0 - momentum) * var);
+            }
+        } else {
+            s_sc[e] = scale[e]; s_sh[e] = shift[e];
+        }
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *xi = x + (long)row2site[i] * m;
+    float acc[HEAD_MAXC];
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c) acc[c] = 0.f;
+    for (int k = 0; k < m; k += 4) {
+        f32x4 v = *(const f32x4 *)(xi + k);
+        const f32x4 sc = *(const f32x4 *)(s_sc + k), sh = *(const f32x4 *)(s_sh + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+#pragma unroll
+        for (int c = 0; c < HEAD_MAXC; ++c)
+            if (c < nc) {
+                const float *w = s_w + c * m + k;
+                acc[c] = fmaf(v[0], w[0], fmaf(v[1], w[1], fmaf(v[2], w[2], fmaf(v[3], w[3], acc[c]))));
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c)
+        if (c < nc) logits[i * nc + c] = acc[c] + s_b[c];
+}
+
+// Backward of the same: per input row  y = relu(x * scale + shift) (recomputed),  g = (dl @ W) masked by y > 0, added onto
+// the row's site (several rows may share one: atomics; gsite zeroed by the caller);  dW += dl^T y, db += sum dl (block sums,
+// then atomics);  the BatchNorm-backward column sums  sum g, sum g * xhat  over the ROWS (= over the sites, by linearity)
+// into the accumulated slab `part` ([slots][2][m] doubles) that urn_bn_bwd_apply_sums then reads.
+#define TAIL_ROWS 128
+__global__ __launch_bounds__(TAIL_ROWS) void k_tail_bwd(const float *__restrict__ dl, const float *__restrict__ x,
+                                                        const int *__restrict__ row2site, long n, int m, int nc,
+                                                        const float *__restrict__ W, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, const float *__restrict__ mean,
+                                                        const float *__restrict__ invstd, float *__restrict__ gsite,
+                                                        float *__restrict__ dW, float *__restrict__ db, double *__restrict__ part,
+                                                        int slots)
+{
+    __shared__ float s_w[HEAD_MAXC * HEAD_MAXM / 8];
+    __shared__ float s_dl[TAIL_ROWS][9];
+    __shared__ float s_y[TAIL_ROWS][TAIL_MAXM / 2 + 1];    // y, then g          (m <= 32 here; wider heads take the unfused route)
+    __shared__ float s_gx[TAIL_ROWS][TAIL_MAXM / 2 + 1];   // g * xhat
+    for (int e = threadIdx.x; e < nc * m; e += TAIL_ROWS) s_w[e] = W[e];
+    const long i = (long)blockIdx.x * TAIL_ROWS + threadIdx.x;
+    const bool ok = i < n;
+    float d[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d[c] = (ok && c < nc) ? dl[i * nc + c] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s_dl[threadIdx.x][c] = d[c];
+    __syncthreads();
+    const long site = ok ? (long)row2site[i] : 0;
+    for (int k = 0; k < m; k += 4) {
+        f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok) xv = *(const f32x4 *)(x + site * m + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k + j;
+            const float y = ok ? fmaxf(fmaf(xv[j], scale[kk], shift[kk]), 0.f) : 0.f;
+            float g = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < nc) g = fmaf(d[c], s_w[c * m + kk], g);
+            if (!(y > 0.f)) g = 0.f;
+            const float xh = (xv[j] - mean[kk]) * invstd[kk];
+            s_y[threadIdx.x][kk] = y;
+            s_gx[threadIdx.x][kk] = g * xh;
+            if (ok && g != 0.f) atomicAdd(&gsite[site * m + kk], g);
+            // (g itself is kept in a register image below: s_y is still needed for dW)
+        }
+    }
+    __syncthreads();
+    // dW / db: thread e = (c, k) sums over the block's rows
+    for (int e = threadIdx.x; e < nc * m; e += TAIL_ROWS) {
+        const int c = e / m, k = e - c * m;
+        float acc = 0.f;
+        for (int r = 0; r < TAIL_ROWS; ++r) acc = fmaf(s_dl[r][c], s_y[r][k], acc);
+        atomicAdd(&dW[e], acc);
+    }
+    if (threadIdx.x < nc) {
+        float acc = 0.f;
+        for (int r = 0; r < TAIL_ROWS; ++r) acc += s_dl[r][threadIdx.x];
+        atomicAdd(&db[threadIdx.x], acc);
+    }
+    __syncthreads();
+    // g again into s_y (recomputed from dl, W and the mask y > 0 that s_y holds)
+    for (int k = 0; k < m; ++k) {
+        float g = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < nc) g = fmaf(d[c], s_w[c * m + k], g);
+        const bool on = s_y[threadIdx.x][k] > 0.f;
+        s_y[threadIdx.x][k] = on ? g : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * m) {
+        const int k = threadIdx.x < m ? threadIdx.x : threadIdx.x - m;
+        double acc = 0.0;
+        if (threadIdx.x < m) { for (int r = 0; r < TAIL_ROWS; ++r) acc += (double)s_y[r][k]; }
+        else { for (int r = 0; r < TAIL_ROWS; ++r) acc += (double)s_gx[r][k]; }
+        const long slot = blockIdx.x % (unsigned)slots;
+        unsafeAtomicAdd(&part[(slot * 2 + (threadIdx.x < m ? 0 : 1)) * m + k], acc);
+    }
+}
+
+extern "C" int urn_tail_fwd(const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W, const float *b,
+                            const double *sums, int slots, int64_t n_sites, double eps, const float *gamma, const float *beta,
+                            float *mean, float *invstd, float *scale, float *shift, float *running_mean, float *running_var,
+                            double momentum, float *logits, void *stream)
+{
+    if (n <= 0) return URN_OK;
+    URN_CHECK_ARG(x && row2site && W && logits && scale && shift, "null pointer");
+    URN_CHECK_ARG(m > 0 && m % 4 == 0 && m <= TAIL_MAXM && nc > 0 && nc <= HEAD_MAXC && nc * m <= HEAD_MAXC * HEAD_MAXM / 8, "unsupported head shape");
+    URN_CHECK_ARG(!sums || (slots > 0 && n_sites > 0 && gamma && beta && mean && invstd), "incomplete statistics");
+    hipLaunchKernelGGL(k_tail_fwd, dim3(urn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, row2site, (long)n, m, nc, W, b, sums, slots,
+                       (long)n_sites, eps, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, momentum, logits);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+extern "C" int urn_tail_bwd(const float *dlogits, const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W,
+                            const float *scale, const float *shift, const float *mean, const float *invstd, float *gsite,
+                            float *dW, float *db, double *part, int slots, void *stream)
+{
+    if (n <= 0) return URN_OK;
+    URN_CHECK_ARG(dlogits && x && row2site && W && scale && shift && mean && invstd && gsite && dW && db && part && slots > 0, "null pointer");
+    URN_CHECK_ARG(m > 0 && m % 4 == 0 && m <= TAIL_MAXM / 2 && nc > 0 && nc <= 8 && nc * m <= HEAD_MAXC * HEAD_MAXM / 8, "unsupported head shape (m <= 32, nc <= 8)");
+    hipLaunchKernelGGL(k_tail_bwd, dim3(urn_cdiv(n, TAIL_ROWS)), dim3(TAIL_ROWS), 0, (hipStream_t)stream, dlogits, x, row2site, (long)n, m, nc,
+                       W, scale, shift, mean, invstd, gsite, dW, db, part, slots);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
 // ---- per-event mean cross-entropy ------------------------------------------------------------
 // pass 1: per row log-softmax CE (optionally weighted) and argmax hit; per-event sums with atomics:
 //         ev[e] = (sum w*ce, row count, hits)   (double, float-exact counts)

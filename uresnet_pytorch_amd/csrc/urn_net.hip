@@ -154,6 +154,10 @@ struct urn_net {
     hipStream_t dw2_stream = nullptr;  // the stream they all run on
     bool side_probed = false;
     bool pairs_armed = false;            // urn_net_set_pairs was called for the coming forward
+    // urn_net_set_head: the Linear head inside the executor (coming forward + its backward)
+    bool head_armed = false, head_live = false;
+    const float *head_w = nullptr, *head_b = nullptr;
+    float *head_logits = nullptr;
     // keep the fastest of g_net_side_probe candidate side streams for this executor's main stream (see probe_pair)
     void pick_side()
     {
@@ -1016,6 +1020,17 @@ extern "C" int urn_net_set_pairs(urn_net *net, int num_levels, const void *const
     return URN_OK;
 }
 
+extern "C" int urn_net_set_head(urn_net *net, const float *W, const float *b)
+{
+    URN_CHECK_ARG(net && W, "null pointer");
+    if (!net->sums_mode() || net->m > 32 || net->nc > 8) {
+        urn_set_error("urn_net_set_head: needs the fused path with accumulated statistics, m <= 32 and num_class <= 8");
+        return URN_EUNSUPPORTED;
+    }
+    net->head_w = W; net->head_b = b; net->head_armed = true;
+    return URN_OK;
+}
+
 static int set_geo(urn_net *net, int num_levels, int64_t ld, const int64_t *n, const void *const *nbr, const void *const *chd,
                    const void *const *up, const int32_t *row2site, int64_t n_rows)
 {
@@ -1057,9 +1072,25 @@ static void run_forward(urn_net *net, const float *site_feats)
         net->u.pre[0].bn1.x = x.x;
         Cons c_out; c_out.bn = &net->bn_out;
         x = net->u_f(net->u, x, 0, c_out);
-        // the last BatchNormReLU feeds the OutputLayer, not a conv: materialise it
+        // the last BatchNormReLU feeds the OutputLayer, not a conv
         BNP &b = net->bn_out;
         b.x = x.x; b.nrows = n0;
+        net->head_live = net->head_armed && net->sums_mode() && (x.st.part != nullptr || !net->training);
+        net->head_armed = false;
+        if (net->head_live) {
+            // ... with the head armed: BatchNormReLU + OutputLayer + Linear in one kernel, straight to the logits
+            net->alloc_bn(b);
+            if (net->live()) {
+                const bool st = x.st.part && net->training;
+                net->check(urn_tail_fwd(x.x, net->geo.row2site, net->geo.n_rows, b.c, net->nc, net->head_w, net->head_b,
+                                        st ? x.st.part : nullptr, st ? x.st.n_part : 0, n0, net->eps, net->params + b.w, net->params + b.b,
+                                        b.mean, b.invstd, b.scale, b.shift, (st && net->running) ? net->running + b.run : nullptr,
+                                        (st && net->running) ? net->running + b.run + b.c : nullptr, net->momentum, net->head_logits, net->st));
+            }
+            net->trunk_out = x.x;   // (marks "a forward was recorded"; the rows themselves are never formed)
+            return;
+        }
+        // ... otherwise materialise it
         if (x.st.part && net->training) {   // accumulated statistics: the slab is a partial slab of SUM_SLOTS rows
             net->alloc_bn(b);
             if (net->live())
@@ -1085,12 +1116,30 @@ static void run_backward(urn_net *net, const float *d_rows)
     const int64_t n0 = net->geo.n[0];
     net->dw2_shared = nullptr; net->dw2_stream = nullptr;
     float *d = net->arena.f32(n0 * net->m);
-    if (net->live()) {
-        net->check(hipMemsetAsync(d, 0, (size_t)n0 * net->m * 4, net->st) == hipSuccess ? URN_OK : URN_EHIP);
-        net->check(urn_rows_scatter_add(d_rows, net->geo.row2site, net->geo.n_rows, net->m, d, net->st));
+    if (net->head_live) {
+        // the armed head: d_rows are the logits' gradients.  One kernel forms the masked gradient of the last BatchNormReLU's
+        // output on the sites (+ the head's parameter gradients + the BatchNorm-backward column sums), the apply finishes it
+        BNP &b = net->bn_out;
+        net->sums_begin();
+        double *part = net->sums_alloc(b.c);
+        float *dx = net->arena.f32(n0 * b.c);
+        if (net->live()) {
+            net->check(hipMemsetAsync(d, 0, (size_t)n0 * net->m * 4, net->st) == hipSuccess ? URN_OK : URN_EHIP);
+            float *gw = net->grads + net->n_params;
+            net->check(urn_tail_bwd(d_rows, b.x, net->geo.row2site, net->geo.n_rows, b.c, net->nc, net->head_w, b.scale, b.shift, b.mean,
+                                    b.invstd, d, gw, gw + (int64_t)net->nc * b.c, part, urn_net::SUM_SLOTS, net->st));
+            net->check(urn_bn_bwd_apply_sums(b.x, d, nullptr, 0, n0, b.c, net->params + b.w, b.mean, b.invstd, part, urn_net::SUM_SLOTS,
+                                             net->grads + b.w, net->grads + b.b, dx, net->st));
+        }
+        d = dx;
+    } else {
+        if (net->live()) {
+            net->check(hipMemsetAsync(d, 0, (size_t)n0 * net->m * 4, net->st) == hipSuccess ? URN_OK : URN_EHIP);
+            net->check(urn_rows_scatter_add(d_rows, net->geo.row2site, net->geo.n_rows, net->m, d, net->st));
+        }
+        d = net->bn_bwd(net->bn_out, d, n0);
+        if (net->sums_mode()) net->sums_begin();
     }
-    d = net->bn_bwd(net->bn_out, d, n0);
-    if (net->sums_mode()) net->sums_begin();
     d = net->fused ? net->u_b(net->u, d, 0) : net->u_bwd(net->u, d, 0);
     net->conv_bwd(net->stem, d, net->geo.nbr[0], net->geo.nbr[0], 1, n0, n0, false);
     // join: the caller's stream continues only after every weight gradient has landed
@@ -1127,9 +1176,10 @@ extern "C" int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const i
     net->arena.reset(ws, (size_t)ws_bytes, false);
     net->params = params; net->running = running; net->training = training; net->st = (hipStream_t)stream;
     net->rc = URN_OK; net->grads = nullptr;
+    net->head_logits = out_rows;
     run_forward(net, site_feats);
     if (net->arena.overflow) { urn_set_error("urn_net_forward: workspace too small (%zu needed so far)", net->arena.peak); return URN_EINVAL; }
-    if (net->rc == URN_OK) net->check(urn_rows_gather(net->trunk_out, row2site, n_rows, net->m, out_rows, net->st));
+    if (net->rc == URN_OK && !net->head_live) net->check(urn_rows_gather(net->trunk_out, row2site, n_rows, net->m, out_rows, net->st));
     return net->rc;
 }
 

@@ -37,6 +37,7 @@ class UResNet(torch.nn.Module):
         self.use_executor = (dimension == 3 and m % 16 == 0)
         self.executor_flags = 0     # lib URN_NET_UNFUSED (1) / URN_NET_SINGLE_STREAM (2) / URN_NET_SLAB_STATS (4): debug and A/B switches
         self._executor = None
+        self.fuse_head = True       # A/B switch: False keeps OutputLayer rows + HeadFunction as separate launches
 
     def _trunk(self, coords, features):
         if self._executor is None:
@@ -52,8 +53,10 @@ class UResNet(torch.nn.Module):
         ex.prepare_weights()      # transposed / fragment-ordered weight copies on the side stream, beside the integer phase
         geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels, defer_sync=True)
         feats = so.input_features(geo, features)
-        ex.prepare(geo, self.training)
-        return ex.forward(geo, feats, self.training)
+        # the Linear head inside the executor (last BatchNormReLU + OutputLayer + Linear = one kernel) where it can be
+        head = (self.linear.weight, self.linear.bias) if (self.fuse_head and ex.head_ok(self.linear.weight, self.linear.bias)) else None
+        ex.prepare(geo, self.training, head)
+        return ex.forward(geo, feats, self.training, head), head is not None
 
     def forward(self, point_cloud):
         """point_cloud: (N, d+2) rows [x, y, z, batch_id, value]; returns [ (N, NUM_CLASS) ]."""
@@ -63,11 +66,14 @@ class UResNet(torch.nn.Module):
             _lib.set_precision(getattr(self._flags, 'PRECISION', 'fp32'))   # flags -prec: fp32 (default) | bf16 | fp16
         # the executor serves training steps and (with the running BatchNorm statistics) inference without gradients;
         # eval mode WITH autograd, hooks and CPU tensors take the per-layer path
+        done = False
         if self.use_executor and coords.is_cuda and (self.training or not torch.is_grad_enabled()):
-            x = self._trunk(coords, features)
+            x, done = self._trunk(coords, features)
         else:
             x = self.sparseModel((coords, features))
-        if x.is_cuda:   # Linear on the HIP head kernel (same parameters: self.linear.weight / .bias)
+        if done:        # the executor ran the head as well: x are the logits
+            pass
+        elif x.is_cuda:   # Linear on the HIP head kernel (same parameters: self.linear.weight / .bias)
             x = so.HeadFunction.apply(x, self.linear.weight, self.linear.bias)
         else:
             x = self.linear(x)

@@ -165,25 +165,34 @@ class TrunkExecutor:
         self.flat, self.running = flat, running
         self.flat_grad = None
 
-    def grad_buffer(self):
+    def grad_buffer(self, tail=()):
         """Flat gradient buffer that every trunk parameter's .grad aliases.  Adopts an existing flat
-        buffer (parallel.FlatGradients) when the .grad tensors already sit at the right offsets."""
-        g0 = self.params[0].grad
+        buffer (parallel.FlatGradients) when the .grad tensors already sit at the right offsets.  `tail`: the head's
+        parameters (homed behind the trunk's by flatten), whose gradients the executor writes right behind the trunk's."""
+        params = list(self.params) + list(tail)
+        offsets = list(self.offsets)
+        o = self.n_params
+        for p in tail:
+            offsets.append(o); o += p.numel()
+        total = o
+        g0 = params[0].grad
         if g0 is not None:
-            base = g0.data_ptr() - 4 * self.offsets[0]
-            if all(p.grad is not None and p.grad.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets)):
+            base = g0.data_ptr() - 4 * offsets[0]
+            if all(p.grad is not None and p.grad.data_ptr() == base + 4 * o for p, o in zip(params, offsets)):
                 return base, None
-        if self.flat_grad is None or self.flat_grad.device != self.flat.device:
-            self.flat_grad = torch.zeros(self.n_params, dtype=torch.float32, device=self.flat.device)
-        fresh = all(p.grad is None for p in self.params)
+        if self.flat_grad is None or self.flat_grad.device != self.flat.device or self.flat_grad.numel() < total:
+            self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.flat.device)
+        fresh = all(p.grad is None for p in params)
         if not fresh:
             # gradients exist elsewhere (accumulation by the user): carry them over once
-            for p, o in zip(self.params, self.offsets):
+            for p, o in zip(params, offsets):
                 if p.grad is not None and p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                     self.flat_grad[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                elif p.grad is None:
+                    self.flat_grad[o:o + p.numel()].zero_()
         else:
             self.flat_grad.zero_()      # zero_grad(set_to_none=True) semantics
-        for p, o in zip(self.params, self.offsets):
+        for p, o in zip(params, offsets):
             p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
         return self.flat_grad.data_ptr(), self.flat_grad
 
@@ -227,8 +236,9 @@ class TrunkExecutor:
         _l.check(_l.load().urn_net_prepare_weights(slot.handle, self.flat.data_ptr(), slot.wbuf.data_ptr(), n3, _l.stream()),
                  'net_prepare_weights')
 
-    def prepare(self, geo, training):
-        """Host-side preparation of forward() that does not need the level counts; call it BEFORE geo.sync()."""
+    def prepare(self, geo, training, head=None):
+        """Host-side preparation of forward() that does not need the level counts; call it BEFORE geo.sync().
+        head = (weight, bias) of the Linear: run inside the executor (urn_net_set_head), the output is then the logits."""
         Lv = geo.num_levels
         slot, self._early_slot = (self._early_slot or self.acquire()), None
         need_bwd = bool(training and torch.is_grad_enabled())
@@ -244,12 +254,22 @@ class TrunkExecutor:
             t_nbr=(ctypes.c_int * Lv)(*[t[1] for t in geo.pairs['nbr']]),
             t_chd=(ctypes.c_int * Lv)(*([t[1] for t in geo.pairs['chd']] + [0])),
             t_up=(ctypes.c_int * Lv)(*([t[1] for t in geo.pairs['up']] + [0])),
-            out=torch.empty((geo.n_rows, self.cfg[0]), dtype=torch.float32, device=geo.device))
+            head=head,
+            out=torch.empty((geo.n_rows, self.cfg[0] if head is None else head[0].shape[0]), dtype=torch.float32, device=geo.device))
 
-    def forward(self, geo, feats, training):
-        """site features -> (n_rows, m) rows in input order.  Recorded for backward when training."""
+    def head_ok(self, weight, bias):
+        """Can the Linear head run inside the executor?  Fused path with accumulated statistics, m <= 32, nc <= 8, and the
+        head's parameters homed right behind the trunk's (flatten(tail=...)), so that their gradients are one buffer."""
+        if self.flags & 5 or self.cfg[0] > 32 or weight.shape[0] > 8 or bias is None or self.flat is None:
+            return False
+        base = self.flat.data_ptr() + 4 * self.n_params
+        return weight.data_ptr() == base and bias.data_ptr() == base + 4 * weight.numel()
+
+    def forward(self, geo, feats, training, head=None):
+        """site features -> (n_rows, m) rows in input order, or the (n_rows, num_class) logits with head = (weight, bias).
+        Recorded for backward when training."""
         need_bwd = bool(training and torch.is_grad_enabled())   # grad mode is off inside Function.forward
-        return _TrunkFunction.apply(feats, self.params[0], self, geo, need_bwd, bool(training))
+        return _TrunkFunction.apply(feats, self.params[0], self, geo, need_bwd, bool(training), head)
 
 
 class _TrunkFunction(torch.autograd.Function):
@@ -258,13 +278,14 @@ class _TrunkFunction(torch.autograd.Function):
     buffer directly (the parameters' .grad tensors alias it)."""
 
     @staticmethod
-    def forward(ctx, feats, anchor, ex, geo, need_bwd, training=True):
+    def forward(ctx, feats, anchor, ex, geo, need_bwd, training=True, head=None):
         L = _l.load()
         Lv = geo.num_levels
-        prep = ex._prep if (ex._prep is not None and ex._prep['geo'] is geo and ex._prep['need_bwd'] == need_bwd) else None
+        prep = ex._prep if (ex._prep is not None and ex._prep['geo'] is geo and ex._prep['need_bwd'] == need_bwd
+                            and (ex._prep['head'] is None) == (head is None)) else None
         ex._prep = None
         if prep is None:
-            ex.prepare(geo, need_bwd)
+            ex.prepare(geo, need_bwd, head)
             prep, ex._prep = ex._prep, None
         slot, nbr, chd, up, out = prep['slot'], prep['nbr'], prep['chd'], prep['up'], prep['out']
         geo.sync()
@@ -273,10 +294,12 @@ class _TrunkFunction(torch.autograd.Function):
         feats = feats.contiguous()
         _l.check(L.urn_net_set_pairs(slot.handle, Lv, prep['p_nbr'], prep['p_chd'], prep['p_up'], prep['t_nbr'], prep['t_chd'],
                                      prep['t_up']), 'net_set_pairs')
+        if head is not None:
+            _l.check(L.urn_net_set_head(slot.handle, head[0].data_ptr(), head[1].data_ptr()), 'net_set_head')
         _l.check(L.urn_net_forward(slot.handle, Lv, geo.ld, n, nbr, chd, up, geo.row2site.data_ptr(), geo.n_rows,
                                    ex.flat.data_ptr(), ex.running.data_ptr(), feats.data_ptr(), ws.data_ptr(),
                                    ws_bytes, out.data_ptr(), int(training), _l.stream()), 'net_forward')
-        ctx.ex, ctx.geo, ctx.ws, ctx.feats, ctx.slot = ex, geo, ws, feats, slot   # keep workspace/inputs alive
+        ctx.ex, ctx.geo, ctx.ws, ctx.feats, ctx.slot, ctx.head = ex, geo, ws, feats, slot, head   # keep workspace/inputs alive
         if need_bwd:
             ctx.token = _Token()
             slot.token = weakref.ref(ctx.token)    # busy until backward ran or the graph is dropped
@@ -286,8 +309,8 @@ class _TrunkFunction(torch.autograd.Function):
     def backward(ctx, d_rows):
         L = _l.load()
         ex = ctx.ex
-        gptr, keep = ex.grad_buffer()
+        gptr, keep = ex.grad_buffer(() if ctx.head is None else ctx.head)
         d_rows = d_rows.contiguous()
         _l.check(L.urn_net_backward(ctx.slot.handle, d_rows.data_ptr(), gptr, _l.stream()), 'net_backward')
         ctx.slot.token = None
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
