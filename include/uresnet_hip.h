@@ -437,6 +437,16 @@ int urn_net_forward(urn_net *net, int num_levels, int64_t ld, const int64_t *n, 
                     const float *params, float *running, const float *site_feats, void *ws, int64_t ws_bytes,
                     float *out_rows, int training, void *stream);
 int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stream);
+/* Overlap of the gradient all-reduce with the backward pass (data-parallel ranks).  The flat buffers are laid out
+ * [stem | encoder levels 0..L-2 | bottom level | decoder levels L-2..0 | last BatchNorm | (head)], and the backward pass
+ * finishes them from the back: [urn_net_suffix_offset, end) is complete when the bottom level's backward has run, the
+ * encoder prefix only at the end.  urn_net_backward_cb is urn_net_backward with a call-back at that point: every kernel that
+ * writes into the suffix has been enqueued -- input gradients and BatchNorm gradients on `stream`, weight gradients on the
+ * executor's side stream (urn_net_side_stream; NULL for a single-stream handle), which has been ordered behind `stream` --
+ * so a collective issued behind the side stream's tail reduces the suffix while the encoder half of the backward pass runs. */
+int64_t urn_net_suffix_offset(const urn_net *net);
+void *urn_net_side_stream(const urn_net *net);
+int urn_net_backward_cb(urn_net *net, const float *d_rows, float *grads, void *stream, void (*bottom_done)(void *), void *user);
 /* Optional, before a forward: the Linear head (reference uresnet_sparse.py:25,36; W (num_class, m) row-major, b (num_class))
  * run INSIDE the executor for the NEXT urn_net_forward and its backward: the last BatchNormReLU, the OutputLayer and the
  * Linear are one kernel (urn_tail_fwd), their gradients one kernel + the BatchNorm's apply (urn_tail_bwd).  out_rows of

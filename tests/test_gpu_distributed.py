@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
     res = t.train_step(_blob(), epoch=0., batch_size=2)
     g = t._grads.flat.detach().cpu().clone()
     p1 = torch.cat([p.detach().flatten() for p in t._net.parameters()]).cpu().clone()
-    q.put((rank, p0.numpy(), g.numpy(), p1.numpy(), float(res['loss_seg']), list(t.last_slots)))
+    q.put((rank, p0.numpy(), g.numpy(), p1.numpy(), float(res['loss_seg']), list(t.last_slots), int(t.last_collectives)))
     torch.distributed.destroy_process_group()
 
 
@@ -53,8 +53,11 @@ def test_two_rank_sparse_data_parallel_on_one_gpu():
     for p in procs: p.start()
     outs = sorted([q.get(timeout=600) for _ in procs], key=lambda o: o[0])
     for p in procs: p.join(120)
-    (_, p0a, ga, p1a, la, sa), (_, p0b, gb, p1b, lb, sb) = outs
+    (_, p0a, ga, p1a, la, sa, ca), (_, p0b, gb, p1b, lb, sb, cb) = outs
     assert sorted(sa + sb) == [0, 1]                   # every event on exactly one rank
+    # the all-reduce ran in TWO pieces: the decoder + bottom + head suffix from inside the backward pass (behind the
+    # executor's side stream), the encoder prefix after it (parallel.OverlappedAllReduce)
+    assert ca == 2 and cb == 2, (ca, cb)
     assert np.array_equal(p0a, p0b)                    # broadcast at initialize()
     assert np.array_equal(ga, gb)                      # identical summed gradient on both ranks
     assert np.array_equal(p1a, p1b)                    # replicas stay in sync after the step

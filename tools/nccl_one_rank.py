@@ -16,9 +16,13 @@ data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['la
 torch.manual_seed(0)
 net = SparseUResNet(flags).to(dev).train()
 g = parallel.FlatGradients(net); opt = parallel.FlatAdam(g, lr=1e-3); crit = SparseSegmentationLoss(flags)
+ov = parallel.OverlappedAllReduce(g, force=True)
 def step(reduce):
-    g.zero(); out = net(data); loss, _ = crit(out, [data], [label], None); loss.backward()
-    if reduce: dist.all_reduce(g.flat, op=dist.ReduceOp.SUM)
+    g.zero(); out = net(data); loss, _ = crit(out, [data], [label], None)
+    if reduce == 2: ov.arm(net)          # the two-piece all-reduce: suffix from inside the backward pass, behind the side stream
+    loss.backward()
+    if reduce == 2: ov.finish()
+    elif reduce: dist.all_reduce(g.flat, op=dist.ReduceOp.SUM)
     opt.step()
 def timeit(reduce, n=40):
     for _ in range(5): step(reduce)
@@ -29,5 +33,6 @@ print('before init_process_group: %.3f ms per step' % timeit(False), flush=True)
 dist.init_process_group(backend='nccl', rank=0, world_size=1)
 print('communicator present, no collective: %.3f ms per step' % timeit(False), flush=True)
 print('one all-reduce (11 MB, world 1) per step: %.3f ms per step' % timeit(True), flush=True)
+print('two-piece all-reduce (suffix overlapped with the backward pass), world 1: %.3f ms per step' % timeit(2), flush=True)
 print('again without: %.3f ms per step' % timeit(False), flush=True)
 dist.destroy_process_group()

@@ -158,6 +158,10 @@ struct urn_net {
     bool head_armed = false, head_live = false;
     const float *head_w = nullptr, *head_b = nullptr;
     float *head_logits = nullptr;
+    // urn_net_backward_cb: called once, when every kernel that writes a gradient of the decoder + bottom suffix of the flat
+    // buffer has been enqueued (and the side stream has been ordered behind the caller's stream at that point)
+    void (*bottom_cb)(void *) = nullptr;
+    void *bottom_user = nullptr;
     // keep the fastest of g_net_side_probe candidate side streams for this executor's main stream (see probe_pair)
     void pick_side()
     {
@@ -705,6 +709,18 @@ struct urn_net {
             }
         }
         for (int i = (int)lv.pre.size() - 1; i >= 0; --i) dy = block_b(lv.pre[i], dy, l);
+        if (!lv.has_sub && bottom_cb && live()) {
+            // bottom level done: the gradients of [bottom blocks | decoder | last BatchNorm | head] -- a contiguous suffix of the
+            // flat buffer (registration order) -- are complete once what is queued so far has run.  Order the side stream
+            // behind the caller's stream here, so that a collective issued on the side stream's tail sees both.
+            dw_flush();
+            if (side && !events.empty()) {
+                hipEvent_t e = events[ev_next++ % events.size()];
+                check(hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess ? URN_OK : URN_EHIP);
+                side_used = true;
+            }
+            bottom_cb(bottom_user);
+        }
         return dy;
     }
 };
@@ -1020,6 +1036,17 @@ extern "C" int urn_net_set_pairs(urn_net *net, int num_levels, const void *const
     return URN_OK;
 }
 
+// first parameter of the bottom level: [that offset, end) of the flat buffers = bottom blocks + decoder + last BatchNorm
+extern "C" int64_t urn_net_suffix_offset(const urn_net *net)
+{
+    if (!net) return -1;
+    const ULevel *lv = &net->u;
+    while (lv->has_sub) lv = lv->sub.get();
+    const Block &k = lv->pre[0];
+    return k.has_nin ? k.nin.w : k.bn1.w;
+}
+extern "C" void *urn_net_side_stream(const urn_net *net) { return net ? (void *)net->side : nullptr; }
+
 extern "C" int urn_net_set_head(urn_net *net, const float *W, const float *b)
 {
     URN_CHECK_ARG(net && W, "null pointer");
@@ -1200,6 +1227,15 @@ extern "C" int urn_net_probe(urn_net *net, void *stream)
 
 // Backward of the last forward on this net (same workspace, same stream): d_rows (n_rows, m) ->
 // grads (flat, ACCUMULATED into; caller zeroes).
+extern "C" int urn_net_backward_cb(urn_net *net, const float *d_rows, float *grads, void *stream, void (*bottom_done)(void *), void *user)
+{
+    URN_CHECK_ARG(net, "null handle");
+    net->bottom_cb = bottom_done; net->bottom_user = user;
+    const int r = urn_net_backward(net, d_rows, grads, stream);
+    net->bottom_cb = nullptr; net->bottom_user = nullptr;
+    return r;
+}
+
 extern "C" int urn_net_backward(urn_net *net, const float *d_rows, float *grads, void *stream)
 {
     URN_CHECK_ARG(net && d_rows && grads && net->trunk_out, "null pointer or no forward recorded");

@@ -155,6 +155,9 @@ SIGNATURES = {
     'urn_net_bn_export': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_net_probe': (c_int, [c_void_p, c_void_p]),
     'urn_net_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'urn_net_suffix_offset': (c_i64, [c_void_p]),
+    'urn_net_side_stream': (c_void_p, [c_void_p]),
+    'urn_net_backward_cb': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'urn_net_set_head': (c_int, [c_void_p, c_void_p, c_void_p]),
     'urn_tail_fwd': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_i64, ctypes.c_double,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double,

@@ -70,6 +70,72 @@ class FlatGradients:
         return None
 
 
+class OverlappedAllReduce:
+    """The gradient all-reduce of a data-parallel step in TWO pieces, the first one overlapped with the backward pass
+    (replaces the reference's DataParallel gradient reduce, uresnet/trainval.py:21-30,152-154).
+
+    The sparse executor finishes the flat gradient buffer from the back: [decoder + bottom level + head] is complete when the
+    bottom level's backward has run (urn_net_suffix_offset), the encoder prefix only at the end.  arm() hooks the executor:
+    at that point the suffix is all-reduced (SUM) asynchronously BEHIND THE EXECUTOR'S SIDE STREAM (which carries the weight
+    gradients and has been ordered behind the caller's stream), while the encoder half of the backward pass -- about half of
+    its time -- still runs; finish() reduces the prefix and joins both before the optimizer reads the gradients.
+    Only for ONE executor backward per step (gradient accumulation over several forwards completes the suffix in the last
+    backward only: arm(expected=k) fires at the k-th).  Without an executor, or when the hook never fires, finish() is the
+    plain single all-reduce."""
+
+    def __init__(self, flat_grads, force=False):
+        self._fg = flat_grads
+        self._force = force           # tools / tests: run the split path at world size 1 as well
+        self._works, self._offset, self._left, self._ex = [], None, 0, None
+
+    def active(self):
+        return self._force or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    def _reduce(self, t):
+        if dist.is_available() and dist.is_initialized():
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
+    def arm(self, model, expected=1):
+        ex = getattr(model, '_executor', None)
+        self._works, self._offset, self._left, self._ex = [], None, expected, ex
+        if ex is None or not self.active():
+            return False
+        ex.suffix_hook = self._on_suffix
+        return True
+
+    def _on_suffix(self, offset, side_stream_ptr):
+        self._left -= 1
+        if self._left > 0:
+            return
+        flat = self._fg.flat
+        if side_stream_ptr:
+            # behind the side stream's tail: the weight gradients of the suffix are queued there
+            with torch.cuda.stream(torch.cuda.ExternalStream(side_stream_ptr, device=flat.device)):
+                w = self._reduce(flat[offset:])
+        else:
+            w = self._reduce(flat[offset:])
+        self._offset = offset
+        if w is not None:
+            self._works.append(w)
+
+    def finish(self):
+        """after backward(): reduce what is left and wait; returns how many collectives ran"""
+        if self._ex is not None:
+            self._ex.suffix_hook = None
+        if not self.active():
+            return 0
+        flat = self._fg.flat
+        w = self._reduce(flat if self._offset is None else flat[:self._offset])
+        if w is not None:
+            self._works.append(w)
+        n = len(self._works)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return n
+
+
 def broadcast_parameters(module, src=0):
     """One broadcast at initialize()/checkpoint load; replicas then stay in sync because every
     rank applies the identical summed gradient."""

@@ -45,17 +45,25 @@ class trainval(object):
         # loss scales every gradient operand -- with -prec fp16 the unscaled ones (1e-6 .. 1e-8 at cfg5 size) fall below
         # fp16's range when they are rounded for the matrix cores; the flat gradient buffer is unscaled in one pass
         scale = float(getattr(self._flags, 'LOSS_SCALE', 1.0) or 1.0)
+        # SUM over ranks (the reference loss is a sum over all events).  Sparse model with ONE executor backward in this step:
+        # the decoder + bottom + head suffix of the flat buffer is all-reduced from inside the backward pass, overlapped with
+        # its encoder half, the prefix behind it (parallel.OverlappedAllReduce); otherwise ONE collective over the whole
+        # buffer behind the backward kernels.  (N > 1 over RCCL is unmeasured on hardware so far -- DESIGN section 5.)
+        overlap = getattr(self, '_overlap', None)
+        armed = has_graph and overlap is not None and getattr(self, '_n_trunk_fwd', 0) >= 1 and \
+            overlap.arm(self._net, expected=self._n_trunk_fwd)
+        self._n_trunk_fwd = 0
         if has_graph:
             if scale != 1.0:
                 total_loss = total_loss * scale
             total_loss.backward()
-            if scale != 1.0:
-                self._grads.flat.mul_(1.0 / scale)
-        # SUM over ranks (the reference loss is a sum over all events): ONE collective over the flat buffer, issued behind
-        # the backward kernels on the caller's stream and complete (stream-ordered) before the optimizer reads the gradients.
-        # (No overlap with the backward pass is claimed here: the buffer is complete only after the weight gradients of the
-        # side stream have been joined.  N > 1 over RCCL is unmeasured on hardware so far -- DESIGN section 5.)
-        self._grads.all_reduce()
+        if armed:
+            self.last_collectives = overlap.finish()
+        else:
+            self._grads.all_reduce()
+            self.last_collectives = 1
+        if has_graph and scale != 1.0:
+            self._grads.flat.mul_(1.0 / scale)        # (after the sum: unscaling commutes with it)
         self.skipped_step = False
         if scale != 1.0:
             # loss scaling: an operand that overflowed at this scale leaves inf / NaN in the gradients, and Adam's moments
@@ -198,6 +206,8 @@ class trainval(object):
                 segmentation = []
                 for d in data:
                     segmentation.extend(self._net(d))
+                if self._flags.TRAIN:
+                    self._n_trunk_fwd = getattr(self, '_n_trunk_fwd', 0) + len(data)
             else:
                 segmentation = list(self._net(torch.stack(data)))
             loss_seg, acc = 0., 0.
@@ -247,6 +257,8 @@ class trainval(object):
         # gradients live in one flat buffer (one memset, one all-reduce per step); on the GPU the Adam step of the
         # reference (trainval.py:37) is one streaming pass over the flat buffers
         self._grads = parallel.FlatGradients(self._net)
+        self._overlap = parallel.OverlappedAllReduce(self._grads, force=bool(os.environ.get('URN_SPLIT_ALLREDUCE'))) \
+            if (use_gpu and 'sparse' in self._flags.MODEL_NAME) else None
         if use_gpu:
             self._optimizer = parallel.FlatAdam(self._grads, lr=self._flags.LEARNING_RATE)
         else:
@@ -271,4 +283,9 @@ class trainval(object):
             iteration = checkpoint['global_step'] + 1
             print('Done.')
         parallel.broadcast_parameters(self._net)
+        # what is alive now (modules, the imported libraries) stays alive: out of the cyclic collector's way, so that its full
+        # passes (~70 ms each on the ~10^6 objects torch brings along, once every ~250 steps; tools/hiccup.py) stay short
+        import gc
+        gc.collect()
+        gc.freeze()
         return iteration

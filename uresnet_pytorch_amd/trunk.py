@@ -54,6 +54,9 @@ class TrunkExecutor:
         self._prep = None
         self._early_slot = None
         self._side_handles = 0
+        # data-parallel overlap (parallel.OverlappedAllReduce): called from inside the backward pass with the offset of the
+        # flat buffers' decoder + bottom suffix and the executor's side stream, once the kernels that write it are enqueued
+        self.suffix_hook = None
 
     # -- handle ------------------------------------------------------------------------
     def _new_handle(self):
@@ -272,6 +275,9 @@ class TrunkExecutor:
         return _TrunkFunction.apply(feats, self.params[0], self, geo, need_bwd, bool(training), head)
 
 
+_BOTTOM_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+
 class _TrunkFunction(torch.autograd.Function):
     """The trunk as one autograd node.  The stem weight rides along as an input only so that
     autograd schedules backward(); parameter gradients are written into the flat gradient
@@ -311,6 +317,21 @@ class _TrunkFunction(torch.autograd.Function):
         ex = ctx.ex
         gptr, keep = ex.grad_buffer(() if ctx.head is None else ctx.head)
         d_rows = d_rows.contiguous()
-        _l.check(L.urn_net_backward(ctx.slot.handle, d_rows.data_ptr(), gptr, _l.stream()), 'net_backward')
+        hook = ex.suffix_hook
+        if hook is None:
+            _l.check(L.urn_net_backward(ctx.slot.handle, d_rows.data_ptr(), gptr, _l.stream()), 'net_backward')
+        else:
+            err = []
+            h = ctx.slot.handle
+
+            def bottom_done(_user):
+                try:
+                    hook(int(L.urn_net_suffix_offset(h)), L.urn_net_side_stream(h))
+                except BaseException as e:      # (an exception cannot cross the C frames: kept and raised below)
+                    err.append(e)
+            cb = _BOTTOM_CB(bottom_done)
+            _l.check(L.urn_net_backward_cb(h, d_rows.data_ptr(), gptr, _l.stream(), ctypes.cast(cb, ctypes.c_void_p), None), 'net_backward')
+            if err:
+                raise err[0]
         ctx.slot.token = None
         return None, None, None, None, None, None, None
