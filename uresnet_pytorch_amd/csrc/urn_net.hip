@@ -24,6 +24,7 @@ int g_net_skip_dw = 0;     // timing only (urn_set_option "net_dbg_skip_dw"): no
 int g_dw_pairs = 0;        // weight gradients on the two-stage pair-list kernel (bitwise reproducible) instead of the atomics kernel (urn_set_option "dw_pairs")
 int g_net_side_probe = 4;   // candidate side streams tried by an executor's first backward (urn_set_option "net_side_probe"; 0/1 = keep the first)
 int g_net_side_verbose = 0;
+int g_net_side2 = 1;        // weight gradients alternate between TWO side streams (urn_set_option "net_side2"): the backward pass is bound by the kernel time queued per stream (cfg3: 1.25 ms on the caller's stream, 1.30 ms of weight gradients); two side streams 2.65 -> 2.59 ms per step
 
 namespace {
 
@@ -43,18 +44,24 @@ double urn_now_ms()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-double probe_pair(hipStream_t main, hipStream_t side, const std::vector<hipEvent_t> &ev, int rounds)
+// side2 != nullptr: the forks alternate between the two side streams, as the weight gradients of a backward pass do
+double probe_pair(hipStream_t main, hipStream_t side, const std::vector<hipEvent_t> &ev, int rounds, hipStream_t side2 = nullptr)
 {
     if (hipStreamSynchronize(main) != hipSuccess) return 1e30;
     const double t0 = urn_now_ms();
     for (int r = 0; r < rounds; ++r) {
         hipEvent_t e = ev[r % ev.size()];
-        if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return 1e30;
-        hipLaunchKernelGGL(k_probe_spin, dim3(64), dim3(64), 0, side, 1500L);          // ~15 us, like a weight gradient
+        hipStream_t tgt = (side2 && (r & 1)) ? side2 : side;
+        if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(tgt, e, 0) != hipSuccess) return 1e30;
+        hipLaunchKernelGGL(k_probe_spin, dim3(64), dim3(64), 0, tgt, 1500L);          // ~15 us, like a weight gradient
         for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_probe_spin, dim3(64), dim3(64), 0, main, 300L);   // the dX chain
     }
     hipEvent_t e = ev[rounds % ev.size()];
     if (hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) return 1e30;
+    if (side2) {
+        hipEvent_t e2 = ev[(rounds + 1) % ev.size()];
+        if (hipEventRecord(e2, side2) != hipSuccess || hipStreamWaitEvent(main, e2, 0) != hipSuccess) return 1e30;
+    }
     if (hipStreamSynchronize(main) != hipSuccess) return 1e30;
     return urn_now_ms() - t0;
 }
@@ -147,6 +154,9 @@ struct urn_net {
     int training = 1;
     hipStream_t st = nullptr;
     hipStream_t side = nullptr;          // weight gradients run here, off the dX -> BN critical path
+    hipStream_t side2 = nullptr;         // ... and here, alternating (g_net_side2)
+    bool side2_used = false;
+    int dw_toggle = 0;
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
     bool side_used = false;
@@ -163,13 +173,12 @@ struct urn_net {
     void (*bottom_cb)(void *) = nullptr;
     void *bottom_user = nullptr;
     // keep the fastest of g_net_side_probe candidate side streams for this executor's main stream (see probe_pair)
-    void pick_side()
+    // the fastest of g_net_side_probe candidate streams (the first one is `have`) beside the executor's main stream
+    hipStream_t pick_one(hipStream_t have, const char *what)
     {
-        side_probed = true;
-        if (g_net_side_probe < 2 || events.size() < 64) return;
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        std::vector<hipStream_t> cand{side};
+        std::vector<hipStream_t> cand{have};
         for (int i = 1; i < g_net_side_probe; ++i) {
             hipStream_t c = nullptr;
             if (hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prio_lo) != hipSuccess) { (void)hipGetLastError(); break; }
@@ -179,13 +188,28 @@ struct urn_net {
         for (size_t i = 0; i < cand.size(); ++i) {
             (void)probe_pair(st, cand[i], events, 4);
             const double ms = std::min(probe_pair(st, cand[i], events, 16), probe_pair(st, cand[i], events, 16));
-            if (g_net_side_verbose) fprintf(stderr, "urn_net: side stream candidate %zu: %.3f ms\n", i, ms);
+            if (g_net_side_verbose) fprintf(stderr, "urn_net: %s candidate %zu: %.3f ms\n", what, i, ms);
             if (ms < best_ms * 0.8) { best_ms = ms; best = (int)i; }   // later candidates must be clearly better
         }
         (void)hipGetLastError();
         for (size_t i = 0; i < cand.size(); ++i)
             if ((int)i != best) { (void)hipStreamSynchronize(cand[i]); (void)hipStreamDestroy(cand[i]); }
-        side = cand[best];
+        return cand[best];
+    }
+    // keep the fastest of g_net_side_probe candidate side streams for this executor's main stream (see probe_pair)
+    void pick_side()
+    {
+        side_probed = true;
+        if (g_net_side_probe < 2 || events.size() < 64) return;
+        side = pick_one(side, "side stream");
+        if (side2) {
+            side2 = pick_one(side2, "second side stream");
+            // the three streams together: a trio that runs the pattern clearly slower than the pair gives the second stream up
+            const double pair = std::min(probe_pair(st, side, events, 16), probe_pair(st, side, events, 16));
+            const double trio = std::min(probe_pair(st, side, events, 16, side2), probe_pair(st, side, events, 16, side2));
+            if (g_net_side_verbose) fprintf(stderr, "urn_net: one side stream %.3f ms, two %.3f ms\n", pair, trio);
+            if (trio > 1.3 * pair) { (void)hipStreamSynchronize(side2); (void)hipStreamDestroy(side2); side2 = nullptr; }
+        }
     }
     float *wt_all = nullptr;             // transposed copy of every conv weight, same offsets as params
     float *wf_fwd = nullptr, *wf_bwd = nullptr;   // wt_all / params once more in MFMA-fragment order (urn_gconv_args.wt_frag)
@@ -555,10 +579,12 @@ struct urn_net {
         if (dw_queue.empty()) return;
         hipStream_t ws = st;
         if (side && !events.empty()) {
+            const bool second = g_net_side2 && side2 && (dw_toggle++ & 1);
+            hipStream_t target = second ? side2 : side;
             hipEvent_t e = events[ev_next++ % events.size()];
-            if (hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess) {
-                ws = side;
-                side_used = true;
+            if (hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(target, e, 0) == hipSuccess) {
+                ws = target;
+                if (second) side2_used = true; else side_used = true;
             }
         }
         for (const DwJob &j : dw_queue) check(dw_call(*j.c, j.xf, j.dy, j.ld_dy, j.tbl_f, j.n_out, ws, j.scratch));
@@ -809,6 +835,7 @@ extern "C" int urn_net_create(int m, int num_levels, int reps, int num_class, do
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
             n->events.push_back(e);
         }
+        if (g_net_side2 && hipStreamCreateWithPriority(&n->side2, hipStreamNonBlocking, prio_lo) != hipSuccess) { n->side2 = nullptr; (void)hipGetLastError(); }
     } else {
         n->side = nullptr;
         (void)hipGetLastError();
@@ -823,6 +850,7 @@ extern "C" void urn_net_destroy(urn_net *n)
     for (auto e : n->events) (void)hipEventDestroy(e);
     if (n->ev_w) (void)hipEventDestroy(n->ev_w);
     if (n->side) (void)hipStreamDestroy(n->side);
+    if (n->side2) (void)hipStreamDestroy(n->side2);
     delete n;
 }
 
@@ -1175,6 +1203,11 @@ static void run_backward(urn_net *net, const float *d_rows)
         hipEvent_t e = net->events[net->ev_next++ % net->events.size()];
         net->check(hipEventRecord(e, net->side) == hipSuccess && hipStreamWaitEvent(net->st, e, 0) == hipSuccess ? URN_OK : URN_EHIP);
         net->side_used = false;
+    }
+    if (net->side2_used && net->live()) {
+        hipEvent_t e = net->events[net->ev_next++ % net->events.size()];
+        net->check(hipEventRecord(e, net->side2) == hipSuccess && hipStreamWaitEvent(net->st, e, 0) == hipSuccess ? URN_OK : URN_EHIP);
+        net->side2_used = false;
     }
 }
 
