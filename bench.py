@@ -12,9 +12,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   roofline     -- dominant kernel (gather-conv MFMA kernel, forward + input-gradient launches):
                   algorithmic FLOPs (2*R*Cin*Cout per launch, R = rules of that launch) divided by
                   the kernel's launch durations measured with HIP events on the launch stream;
-  cpu_baseline -- an SCN-style fp32 CPU restatement (oracle/cpu_port.py, a port: the reference's own sparse path cannot
-                  run without sparseconvnet): per offset gather -> sgemm -> scatter-add on all host cores, forward +
-                  backward of the same event, 2 warm-ups + median of 5.
+  cpu_baseline -- an SCN-style fp32 CPU restatement (oracle/cpu_port.py + oracle/cpu_fast.c, a port: the reference's own
+                  sparse path cannot run without sparseconvnet): the gather convolutions in C with OpenMP on the host
+                  cores (thread count = fastest of a sweep up to all of them), forward + backward of the same event,
+                  2 warm-ups + median of 5.
 """
 import argparse
 import ctypes
@@ -209,10 +210,14 @@ def main():
             P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if 'running' not in k}
             med, ts, threads = cpu_port.time_step(P, FILTERS, STRIDES, NCLASS, SPATIAL, blob['data'], blob['label'],
                                                   warmup=2, repeats=5, threads='auto')
+            omp = getattr(cpu_port.time_step, 'last_kernel', 'torch') == 'omp'
             cpu = {'value': round(voxels_per_rank / med, 1), 'unit': 'active-voxels/s', 'cores': threads, 'kind': 'port',
                    'sample': '%d-voxel event(s) of the bench, forward+backward, 2 warm-ups + median of 5 (%.3f s; all: %s)'
                              % (voxels_per_rank, med, ' '.join('%.3f' % t for t in ts)),
-                   'method': 'fp32 per-offset gather -> torch.mm -> scatter-add with the oracle rulebook, torch CPU autograd; '
+                   'method': ('fp32 gather convolution in C with OpenMP (oracle/cpu_fast.c: one parallel loop over tiles of 64 output '
+                              'rows, offset by offset inside a tile; private weight-gradient copies per thread), BatchNorm / head / '
+                              'loss as torch CPU ops, the oracle rulebook; ' if omp else
+                              'fp32 per-offset gather -> torch.mm -> scatter-add with the oracle rulebook, torch CPU autograd; ') +
                              'thread count = fastest of a one-pass sweep: ' +
                              ', '.join('%d thr %.2f s' % kv for kv in sorted(cpu_port.time_step.last_sweep.items())),
                    'host_cpus': os.cpu_count()}

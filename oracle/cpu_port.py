@@ -4,6 +4,10 @@ SURVEY.md App. A) on the host cores.
 
 TEST / MEASUREMENT INFRASTRUCTURE ONLY: nothing under uresnet_pytorch_amd/ imports this module.
 
+Two forms of the convolutions (`kernel=`): 'omp' (default when liboracle_cpu.so is built) -- oracle/cpu_fast.c, the gather
+convolution as ONE OpenMP loop over tiles of output rows, offset by offset inside a tile, fp32, all host cores, private
+weight-gradient copies reduced at the end; 'torch' -- the per-offset index_select -> mm -> index_add_ form below.
+
 How SparseConvNet computes on a CPU (the reference's own CPU path, which cannot run here: the library is absent): the
 rulebook is built on the host, and every convolution is, per filter offset, a gather of the input rows of that offset's
 rules, one dense sgemm with W[offset], and a scatter-add into the output rows; BatchNorm is a pass over the (N, C) row
@@ -13,6 +17,8 @@ accumulates in fp64 and is written for checking, not for speed.  The rulebook co
 integer phase is not what this baseline times: only forward + backward, like the metric).
 
 Its results are checked against the oracle in tests/test_oracle_sparse.py (logits and gradients, 1e-4)."""
+import ctypes
+import os
 import time
 
 import numpy as np
@@ -22,10 +28,61 @@ import torch.nn.functional as F
 from . import sparse_oracle as orc
 
 BN_EPS = 1e-4
+_FAST = None
+
+
+def fast_lib():
+    """oracle/liboracle_cpu.so (cpu_fast.c), or None when it has not been built"""
+    global _FAST
+    if _FAST is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'liboracle_cpu.so')
+        if not os.path.exists(path):
+            _FAST = False
+        else:
+            L = ctypes.CDLL(path)
+            vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+            L.cpuf_gconv.argtypes = [vp, vp, vp, i64, ci, ci, i64, ci, ci, ci, vp]
+            L.cpuf_gconv_dw.argtypes = [vp, vp, vp, i64, ci, i64, ci, ci, vp]
+            L.cpuf_set_threads.argtypes = [ci]
+            L.cpuf_max_threads.restype = ci
+            _FAST = L
+    return _FAST or None
+
+
+class _FastConv(torch.autograd.Function):
+    """y = gather-conv(x, W) on cpu_fast.c; tbl (K, n_out) int32 forward table, inv (K, n_in) its inverse, flip_b as in
+    uresnet_pytorch_amd.sparse_ops.GConvFunction (a submanifold table is its own inverse with the offsets mirrored)"""
+
+    @staticmethod
+    def forward(ctx, x, W, tbl, inv, flip_b, n_out):
+        L = fast_lib()
+        x = x.contiguous(); W = W.contiguous()
+        K, cin, cout = W.shape
+        y = torch.empty((n_out, cout), dtype=torch.float32)
+        L.cpuf_gconv(x.data_ptr(), W.data_ptr(), tbl.data_ptr(), tbl.shape[1], K, 0, n_out, cin, cout, 0, y.data_ptr())
+        ctx.save_for_backward(x, W)
+        ctx.t = (tbl, inv, flip_b, n_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        tbl, inv, flip_b, n_out = ctx.t
+        L = fast_lib()
+        K, cin, cout = W.shape
+        dy = dy.contiguous()
+        n_in = x.shape[0]
+        dx = torch.empty((n_in, cin), dtype=torch.float32)
+        # dx[i] = sum_o dy[inv[o][i]] @ W[o]^T: the same loop, gathering cout channels, W[o] read as (cout, cin)^T
+        L.cpuf_gconv(dy.data_ptr(), W.data_ptr(), inv.data_ptr(), inv.shape[1], K, int(flip_b), n_in, cout, cin, 1, dx.data_ptr())
+        dw = torch.zeros_like(W)
+        L.cpuf_gconv_dw(x.data_ptr(), dy.data_ptr(), tbl.data_ptr(), tbl.shape[1], K, n_out, cin, cout, dw.data_ptr())
+        return dx, dw, None, None, None, None
 
 
 class CpuPort:
-    def __init__(self, params, m, num_strides, num_class, spatial, reps=2):
+    def __init__(self, params, m, num_strides, num_class, spatial, reps=2, kernel=None):
+        self.kernel = kernel or ('omp' if fast_lib() is not None else 'torch')
         self.P = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(True) for k, v in params.items()}
         self.m, self.L, self.nc, self.spatial, self.reps = m, num_strides, num_class, spatial, reps
         self.planes = [i * m for i in range(1, num_strides + 1)]
@@ -45,15 +102,24 @@ class CpuPort:
         feats = pc[:, 4:5].astype(np.float32)
         g = orc.Geometry(coords, feats, self.spatial, self.L, mode=3)
         self.n = g.n
-        self.nbr = [self._rules(t) for t in g.nbr]
-        self.chd = [self._rules(t) for t in g.chd]
-        self.up = [self._rules(t) for t in g.up]
+        if self.kernel == 'omp':
+            # dense tables + their inverses (submanifold: itself mirrored; strided: chd and up are each other's inverse)
+            T = lambda t: torch.from_numpy(np.ascontiguousarray(t.astype(np.int32)))
+            self.nbr = [(T(t), T(t), 1) for t in g.nbr]
+            self.chd = [(T(c), T(u), 0) for c, u in zip(g.chd, g.up)]
+            self.up = [(T(u), T(c), 0) for c, u in zip(g.chd, g.up)]
+        else:
+            self.nbr = [self._rules(t) for t in g.nbr]
+            self.chd = [self._rules(t) for t in g.chd]
+            self.up = [self._rules(t) for t in g.up]
         self.feats = torch.from_numpy(g.feats)
         self.row2site = torch.from_numpy(g.row2site.astype(np.int64))
 
     # -- operators -----------------------------------------------------------------------------------------------
-    @staticmethod
-    def _conv(x, W, rules, n_out):
+    def _conv(self, x, W, rules, n_out):
+        if self.kernel == 'omp':
+            tbl, inv, flip_b = rules
+            return _FastConv.apply(x, W, tbl, inv, flip_b, n_out)
         y = torch.zeros((n_out, W.shape[2]), dtype=torch.float32)
         for o, (i_in, i_out) in enumerate(rules):
             if i_in.numel():
@@ -115,18 +181,25 @@ def time_step(params, m, num_strides, num_class, spatial, data, label, warmup=2,
     port.set_geometry(data)
     before = torch.get_num_threads()
     sweep = {}
+    L = fast_lib() if port.kernel == 'omp' else None
+    omp_before = L.cpuf_max_threads() if L is not None else 0
+
+    def set_threads(c):
+        torch.set_num_threads(min(c, 64))       # (BatchNorm / head / loss passes: torch ops on small matrices)
+        if L is not None:
+            L.cpuf_set_threads(c)
     if threads == 'auto':
-        import os
         ncpu = os.cpu_count() or before
-        for c in [c for c in (8, 16, 32, 64) if c <= ncpu] or [before]:
-            torch.set_num_threads(c)
+        cands = (8, 16, 32, 64, 128, 192, 256) if L is not None else (8, 16, 32, 64)
+        for c in [c for c in cands if c <= ncpu] or [before]:
+            set_threads(c)
             port.step(data, label)
             t0 = time.perf_counter()
             port.step(data, label)
             sweep[c] = time.perf_counter() - t0
         threads = min(sweep, key=sweep.get)
     if threads:
-        torch.set_num_threads(int(threads))
+        set_threads(int(threads))
     try:
         for _ in range(warmup):
             port.step(data, label)
@@ -135,8 +208,11 @@ def time_step(params, m, num_strides, num_class, spatial, data, label, warmup=2,
             t0 = time.perf_counter()
             port.step(data, label)
             ts.append(time.perf_counter() - t0)
-        used = int(torch.get_num_threads())
+        used = int(threads) if (threads and L is not None) else int(torch.get_num_threads())
     finally:
         torch.set_num_threads(before)
+        if L is not None:
+            L.cpuf_set_threads(omp_before)
     time_step.last_sweep = sweep
+    time_step.last_kernel = port.kernel
     return float(np.median(ts)), ts, used

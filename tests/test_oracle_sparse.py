@@ -213,15 +213,17 @@ def test_cpu_port_matches_oracle():
     logits_ref = ref.forward(blob['data'])
     loss_ref, _, dl = so.segmentation_loss(logits_ref, blob['data'], blob['label'])
     G, _ = ref.backward(dl)
-    port = cpu_port.CpuPort(P, m, L, nc, S)
-    port.set_geometry(blob['data'])
-    logits, loss = port.step(blob['data'], blob['label'])
-
     def rel(a, b):
         return float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))
-    assert rel(logits.numpy(), logits_ref) < 1e-4
-    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
-    for k, g in G.items():
-        assert rel(port.P[k].grad.numpy(), g) < 2e-3, (k, rel(port.P[k].grad.numpy(), g))
+    assert cpu_port.fast_lib() is not None, 'oracle/liboracle_cpu.so not built (make -C oracle)'
+    for kernel in ('omp', 'torch'):       # cpu_fast.c (OpenMP gather convolution, what bench.py times) and the torch-op form
+        port = cpu_port.CpuPort(P, m, L, nc, S, kernel=kernel)
+        assert port.kernel == kernel
+        port.set_geometry(blob['data'])
+        logits, loss = port.step(blob['data'], blob['label'])
+        assert rel(logits.numpy(), logits_ref) < 1e-4, kernel
+        assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+        for k, g in G.items():
+            assert rel(port.P[k].grad.numpy(), g) < 2e-3, (kernel, k, rel(port.P[k].grad.numpy(), g))
     med, ts, threads = cpu_port.time_step(P, m, L, nc, S, blob['data'], blob['label'], warmup=1, repeats=2)
     assert med > 0 and len(ts) == 2 and threads >= 1
