@@ -190,14 +190,14 @@ def main():
         # HBM traffic of the same kernel: measured in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) and
         # committed under profiles/ (bench.py cannot read PMC counters itself); null when no measurement is committed
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
         if os.path.exists(tpath):
             traffic = round(json.load(open(tpath)).get('gconv_traffic_bytes_per_launch', 0.0)) or None
         roofline = {
             'bound': 'mfma', 'kernel': 'k_gconv_pairs<KC,NC,XF,DEEP,PREC> (compacted rule lists) / k_gconv_tile<KS,RB,CB> by shape: all gather-conv forward + input-gradient launches',
             'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic,
-            'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json)',
+            'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r03_pmc_traffic.json)',
             'launches_per_step': int(n.value // PSTEPS), 'avg_launch_us': round(1e3 * ms.value / max(n.value, 1), 2),
             'algorithmic_gflop_per_step': round(flops_step / 1e9, 3),
         }
