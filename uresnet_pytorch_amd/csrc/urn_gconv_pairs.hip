@@ -222,6 +222,21 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
     const int pw_t = (int)((long)tile * urn_pairs_words(K, T)) + URN_PAIRS_HDR;   // word index of blk_t[0] / blk_p[0] in g.pairs
     const int pw_p = pw_t + (int)urn_pairs_tpad(K, T);
     const int ldxb = (int)g.ldx * 4;
+    // strip variant: the pair words and table rows of the TILE's first blocks are requested HERE -- wave w takes blocks
+    // [16 w, 16 w + 16), whatever the tile's block count turns out to be: the request does not wait for the header, so the
+    // head of the launch is two dependent round trips (header + pair words, then rows), not three.  They are parked in ONE
+    // strip per workgroup behind the statistics prologue and the slab zero-fill; tiles with more blocks than the waves
+    // cover fetch the rest once the header is there.
+    typedef int urn_i32x4 __attribute__((ext_vector_type(4)));
+    urn_i32x4 sw0 = (urn_i32x4){0, 0, 0, 0};
+    int stw = 0;
+    if constexpr (DEEP == 2) {
+        if (wave * 16 < g.p_strip) {
+            sw0 = __builtin_bit_cast(urn_i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane * 16, (pw_p + wave * 256) * 4, 0));
+            if (lane < 16) stw = __builtin_amdgcn_raw_buffer_load_b32(rs_p, lane * 4, (pw_t + wave * 16) * 4, 0);
+        }
+    }
+
     const int b0 = __builtin_amdgcn_readfirstlane(nblk * gi / G);
     // (g.dbg: timing-only ablations of whole phases, tools/bench_pairs.py abl: 32 = no block loop, 64 = return before the epilogue,
     //  128 = one block per wave)
@@ -292,7 +307,29 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
     for (int row = q; row <= T; row += 4)
 #pragma unroll
         for (int c = 0; c < NC; ++c) slab[(long)row * LDW + 16 * c + r] = 0.f;
-    if constexpr (XF != 0) __syncthreads();
+    if constexpr (DEEP == 2) {
+        // (16-byte aligned: the strip starts at the next multiple of four words behind the epilogue's doubles: p_strip blocks of
+        //  16 words, then their p_strip table rows; p_strip a multiple of 16, at least the longest list of a tile)
+        int *strip_e = (int *)smem + (((long)((int *)(s_p + 2 * (long)G * cw) - (int *)smem) + 3) & ~3L);
+        int *strip_te = strip_e + (long)g.p_strip * 16;
+        const int nw = nthreads >> 6;
+        if (wave * 16 < g.p_strip) {
+            *(urn_i32x4 *)(strip_e + wave * 256 + lane * 4) = sw0;
+            if (lane < 16) strip_te[wave * 16 + lane] = stw;
+        }
+        for (int c = 16 * nw; c < nblk; c += 16 * nw) {      // workgroup-uniform: lists longer than the waves covered
+            const int ch = c / 16 + wave;
+            if (ch * 16 < nblk && ch * 16 < g.p_strip) {
+                const urn_i32x4 w = __builtin_bit_cast(urn_i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane * 16, (pw_p + ch * 256) * 4, 0));
+                int tw = 0;
+                if (lane < 16) tw = __builtin_amdgcn_raw_buffer_load_b32(rs_p, lane * 4, (pw_t + ch * 16) * 4, 0);
+                *(urn_i32x4 *)(strip_e + ch * 256 + lane * 4) = w;
+                if (lane < 16) strip_te[ch * 16 + lane] = tw;
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (XF != 0 && DEEP != 2) __syncthreads();
     URN_STAMP(1);
 
     // pair word of block b for lane (r, q): pair r of the block = input row | row in the tile << 24.  With the weights as
@@ -449,29 +486,16 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
         // STRIP variant (one channel chunk: cin = 16 KC; launcher: bit KC of `pairs_v3`).  What a CU's vector-memory path can
         // take is instructions, not bytes (any wave-wide load holds the address unit >= 16 cycles): the loop above issues
         // three dword loads per block for the pair words and the table row next to KC row loads and KC * NC weight loads.
-        // Here the pair words and table rows of the wave's WHOLE share are copied once into a wave-private LDS strip with
-        // 16-byte loads (one per 16 blocks); per block the loop reads them back (ds_read_b32), so its vector-memory
-        // instructions are the gathered rows and the weight blocks only.  The weight block of the next block, when its
+        // Here the pair words and table rows of the TILE are copied once into one LDS strip per workgroup with 16-byte loads
+        // (one per wave and 16 blocks, requested at the kernel's head without waiting for the header, see above); per block
+        // the loop reads them back (ds_read_b32), so its vector-memory instructions are the gathered rows and the weight
+        // blocks only.  The weight block of the next block, when its
         // offset differs, is requested together with the next block's rows BEFORE this block's MFMAs (second register set,
         // copied over behind the MFMAs; KC <= 4) -- one round trip per block where the loop above has two dependent ones
         // (weights at the head, rows at the tail).  The old slab values are the MFMA's C operand: no zero-fill, no adds.
-        // (16-byte aligned: the strips start at the next multiple of four words behind the epilogue's doubles; 17 p_strip words
-        //  per wave, p_strip a multiple of 16)
-        int *strip = (int *)smem + (((long)((int *)(s_p + 2 * (long)G * cw) - (int *)smem) + 3) & ~3L) + (long)wave * ((long)g.p_strip * 17);
-        int *strip_t = strip + (long)g.p_strip * 16;
+        const int *strip = (const int *)smem + (((long)((int *)(s_p + 2 * (long)G * cw) - (int *)smem) + 3) & ~3L) + (long)b0 * 16;   // the wave's share of the workgroup's strip
+        const int *strip_t = (const int *)smem + (((long)((int *)(s_p + 2 * (long)G * cw) - (int *)smem) + 3) & ~3L) + (long)g.p_strip * 16 + b0;
         const int nb = b1 - b0;
-        for (int c = 0; c < nb; c += 32) {      // wave-uniform; one pass for shares of up to 32 blocks
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            const int so = (pw_p + (b0 + c) * 16) * 4;
-            i32x4 w0 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane * 16, so, 0));
-            i32x4 w1 = w0;
-            if (c + 16 < nb) w1 = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane * 16, so + 1024, 0));
-            int tw = 0;
-            if (lane < 32 && c + lane < nb) tw = __builtin_amdgcn_raw_buffer_load_b32(rs_p, lane * 4, (pw_t + b0 + c) * 4, 0);
-            *(i32x4 *)(strip + c * 16 + lane * 4) = w0;
-            if (c + 16 < nb) *(i32x4 *)(strip + (c + 16) * 16 + lane * 4) = w1;
-            if (lane < 32 && c + lane < nb) strip_t[c + lane] = tw;
-        }
         URN_STAMP(5);
         if (nb > 0) {
             constexpr bool W2 = KC * NC <= 4;     // second weight register set (16 KC NC bytes per lane)
@@ -827,11 +851,11 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     if (g_pairs_cbg > 0 && cbg_all % g_pairs_cbg == 0 && g_pairs_cbg <= maxw) cbg = g_pairs_cbg;
     int gy = cbg_all / cbg, cw = 16 * nc * cbg;
     const int maxb = (int)urn_pairs_maxb(a.K, T);
-    auto strip_blocks = [&](int G) { return (((maxb + G - 1) / G + 1) + 15) & ~15; };   // longest share of a tile's block list, rounded up to whole 16-block fills
+    auto strip_blocks = [&](int) { return (maxb + 15) & ~15; };   // ONE strip per workgroup: the longest list a tile can have, in whole 16-block fills
     auto lds_bytes = [&](int G) {
         size_t w = (size_t)2 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
         return w * 4 + (size_t)2 * G * cw * 8 + (deep ? (size_t)cbg * G * URN_PAIRS_IDXB * 17 * 4 : 0) +
-               (strip ? (size_t)cbg * G * strip_blocks(G) * 17 * 4 + 16 : 0);
+               (strip ? (size_t)strip_blocks(G) * 17 * 4 + 16 : 0);
     };
     int G = 1;
     const int want_waves = (a.epi != 2 && g_pairs_waves_fwd > 0) ? g_pairs_waves_fwd : g_pairs_waves;
