@@ -367,6 +367,11 @@ int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *dy, int64_t 
                  void *stream);
 int urn_dense_fold(const float *dxp, float *dx, int batch, const int *dims, const int *pad_lo, const int *pad_hi, int c,
                    void *stream);
+/* Both weight layouts urn_dense_conv reads -- forward [tap][cout_p][cin_p], input gradient [tap][cin_p][cout_p], channel
+ * counts zero-padded -- of n convolutions in ONE launch, from torch's parameter layouts: descs = n records of 11 int64:
+ * src, fwd, bwd (device pointers), taps, transposed (0: nn.Conv (cout, cin, taps); 1: nn.ConvTranspose (cin, cout, taps)),
+ * cin, cout, cin_p, cout_p, 0, 0. */
+int urn_dense_weight_layouts(int n, const int64_t *descs, void *stream);
 /* Row passes around the convolutions (reference uresnet_dense.py:72-83: conv -> BatchNorm(batch statistics) [-> + shortcut]
  * [-> ReLU]); (n, c) fp32 row matrices, c % 4 == 0 and 256 % (c / 4) == 0.
  * urn_dense_bn_act_fwd:  out = [relu](raw * scale + shift [+ res | + res * res_scale + res_shift]) in ONE pass; res NULL =

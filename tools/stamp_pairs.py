@@ -78,7 +78,7 @@ if L.urn_set_option(b'gconv_stamp_ptr', st.data_ptr()) == 0:
         us = lambda v: v / clk * 1e6
         end = np.where(s[:, 6] != 0, s[:, 6], s[:, 4])
         print('  %d waves; entry spread %.2f us; kernel span %.2f us' % (len(s), us(s[:, 0].max() - t0), us(end.max() - t0)))
-        segs = [('prologue', 0, 1), ('strip fill', 1, 5), ('block loop', 5, 2), ('barrier wait', 2, 3), ('epilogue rows', 3, 4), ('statistics tail', 4, 6)]
+        segs = [('  header wait', 0, 7), ('  rest of it', 7, 1), ('prologue', 0, 1), ('strip fill', 1, 5), ('block loop', 5, 2), ('barrier wait', 2, 3), ('epilogue rows', 3, 4), ('statistics tail', 4, 6)]
         for nm, i, j in segs:
             ok = (s[:, i] != 0) & (s[:, j] != 0)
             if not ok.any():

@@ -345,3 +345,74 @@ extern "C" int urn_dense_ce_bwd(const float *logits, int64_t ld, const float *la
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
+
+// ---- batched weight layouts --------------------------------------------------------------------------------------------
+// The dense convolution kernels read their weights as [tap][cout_p][cin_p] (forward) and [tap][cin_p][cout_p] (input
+// gradient), channel counts zero-padded to multiples of 16; torch keeps nn.Conv's as (cout, cin, taps) and
+// nn.ConvTranspose's as (cin, cout, taps).  One launch writes both layouts of EVERY convolution of the model (the Python
+// route made them with a permute + contiguous copy per convolution and pass: ~120 launches and 1.2 ms per cfg2 step).
+#define URN_WL_MAX 64
+struct WLDesc { const float *src; float *fwd, *bwd; int d0, d1, taps, transposed, cin, cout, cin_p, cout_p; };
+struct WLDescs { int n; WLDesc d[URN_WL_MAX]; };
+
+// Workgroup = a 16 x 16 tile of (cout, cin) channel pairs with all their taps, staged through LDS so that the source rows
+// (taps contiguous, then the second channel index) and BOTH destinations (cin contiguous / cout contiguous) move in 64-byte
+// pieces.  The one-element-per-thread form wrote one of the two layouts with a stride of a whole channel row: 0.73 ms per
+// cfg2 step for 600 MB.
+#define WL_T 16
+#define WL_MAXTAPS 27
+__global__ __launch_bounds__(256) void k_dense_weight_layouts(WLDescs t)
+{
+    __shared__ float s_w[WL_T][WL_T][WL_MAXTAPS + 1];      // [co][ci][tap]
+    const WLDesc d = t.d[blockIdx.y];
+    const int tiles_ci = d.cin_p / WL_T, tiles_co = d.cout_p / WL_T;
+    const int taps = d.taps;
+    for (int tile = blockIdx.x; tile < tiles_ci * tiles_co; tile += gridDim.x) {      // workgroup-uniform
+        const int co0 = (tile / tiles_ci) * WL_T, ci0 = (tile % tiles_ci) * WL_T;
+        // load: the 16 x 16 pairs' taps; a pair's taps are contiguous, consecutive pairs along the source's second index too
+        for (int e = threadIdx.x; e < WL_T * WL_T * taps; e += 256) {
+            const int tt = e % taps, p = e / taps;
+            // p runs along the source's contiguous channel index first: Conv (cout, cin, taps) -> ci; ConvTranspose (cin, cout, taps) -> co
+            const int a = p / WL_T, b = p % WL_T;
+            const int co = d.transposed ? co0 + b : co0 + a, ci = d.transposed ? ci0 + a : ci0 + b;
+            float v = 0.f;
+            if (co < d.cout && ci < d.cin)
+                v = d.src[(d.transposed ? ((long)ci * d.cout + co) : ((long)co * d.cin + ci)) * taps + tt];
+            s_w[co - co0][ci - ci0][tt] = v;
+        }
+        __syncthreads();
+        // store: forward [tap][cout_p][cin_p] (ci contiguous), input gradient [tap][cin_p][cout_p] (co contiguous)
+        for (int e = threadIdx.x; e < WL_T * WL_T * taps; e += 256) {
+            const int x = e % WL_T, y = (e / WL_T) % WL_T, tt = e / (WL_T * WL_T);
+            d.fwd[((long)tt * d.cout_p + co0 + y) * d.cin_p + ci0 + x] = s_w[y][x][tt];
+            d.bwd[((long)tt * d.cin_p + ci0 + y) * d.cout_p + co0 + x] = s_w[x][y][tt];
+        }
+        __syncthreads();
+    }
+}
+
+// descs: n records of 11 int64 each: src, fwd, bwd (device pointers), taps, transposed, cin, cout, cin_p, cout_p, 0, 0
+extern "C" int urn_dense_weight_layouts(int n, const int64_t *descs, void *stream)
+{
+    URN_CHECK_ARG(n >= 0 && (n == 0 || descs), "null pointer");
+    for (int base = 0; base < n; base += URN_WL_MAX) {
+        WLDescs t;
+        t.n = n - base < URN_WL_MAX ? n - base : URN_WL_MAX;
+        long big = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const int64_t *r = descs + (int64_t)(base + i) * 11;
+            WLDesc &d = t.d[i];
+            d.src = (const float *)(uintptr_t)r[0]; d.fwd = (float *)(uintptr_t)r[1]; d.bwd = (float *)(uintptr_t)r[2];
+            d.taps = (int)r[3]; d.transposed = (int)r[4]; d.cin = (int)r[5]; d.cout = (int)r[6]; d.cin_p = (int)r[7]; d.cout_p = (int)r[8];
+            d.d0 = d.d1 = 0;
+            URN_CHECK_ARG(d.src && d.fwd && d.bwd && d.taps > 0 && d.taps <= WL_MAXTAPS && d.cin > 0 && d.cout > 0 && d.cin_p >= d.cin &&
+                          d.cout_p >= d.cout && d.cin_p % 16 == 0 && d.cout_p % 16 == 0, "bad record (taps <= 27, padded channel counts multiples of 16)");
+            const long tiles = (long)(d.cin_p / WL_T) * (d.cout_p / WL_T);
+            if (tiles > big) big = tiles;
+        }
+        unsigned gx = (unsigned)(big > 64 ? 64 : (big < 1 ? 1 : big));     // up to 64 workgroups per convolution walk its tiles
+        hipLaunchKernelGGL(k_dense_weight_layouts, dim3(gx, t.n), dim3(256), 0, (hipStream_t)stream, t);
+    }
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
     //  128 = one block per wave)
     const int b1 = __builtin_amdgcn_readfirstlane(URN_DBG(g, 32) ? b0 : (URN_DBG(g, 128) ? min(b0 + 1, nblk * (gi + 1) / G) : nblk * (gi + 1) / G));   // nblk <= 27 * 8, G <= 16
 
+    URN_STAMP(7);   // (the header has arrived: b0 / b1 are scalars)
     // GATHER MAPPING.  The MFMA wants lane (r, q) to hold channels 4q..4q+3 of pair r -- but a wave-load in that shape costs the
     // CU ~66 cycles whatever the cache level (tools/ubench/gather_map.hip): the texture addresser takes the lanes four at a time,
     // and four consecutive lanes are four different rows = four lines.  Loaded row-major instead -- lane l reads piece l & 3 of

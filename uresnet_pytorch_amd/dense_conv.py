@@ -120,6 +120,64 @@ def _colsum(rows, c):
     return part[:n_part.value * 2 * cp].reshape(n_part.value, 2, cp)[:, 0, :c].sum(0).float()
 
 
+# ---- weight layouts of the whole model in one launch -------------------------------------------------------------------
+# urn_dense_conv reads [tap][cout_p][cin_p] (forward) and [tap][cin_p][cout_p] (input gradient); torch keeps (cout, cin, taps)
+# / (cin, cout, taps).  prepare_weights() -- called by the model at the head of a forward pass -- writes both layouts of every
+# convolution with ONE launch into persistent buffers (a permute + contiguous per convolution and pass otherwise: ~120
+# launches per cfg2 step); the autograd Functions below look their operand up by the parameter's identity and fall back to
+# the per-call copies for weights nobody prepared (direct calls in tests).
+class _WeightLayouts(object):
+    def __init__(self):
+        self.key, self.entries, self.descs, self.buf, self.valid = None, {}, None, None, False
+
+    def prepare(self, convs):
+        """convs: list of (weight parameter, transposed) in any order"""
+        import numpy as np
+        key = tuple((id(w), w.data_ptr(), tuple(w.shape), bool(t)) for w, t in convs)
+        if key != self.key:
+            total, plan = 0, []
+            for w, t in convs:
+                d0, d1 = w.shape[0], w.shape[1]
+                taps = w.numel() // (d0 * d1)
+                cin, cout = (d0, d1) if t else (d1, d0)
+                cin_p, cout_p = cin + (-cin) % 16, cout + (-cout) % 16
+                n = taps * cin_p * cout_p
+                plan.append((w, t, taps, cin, cout, cin_p, cout_p, total, total + n))
+                total += 2 * n
+            self.buf = torch.empty(total, dtype=torch.float32, device=convs[0][0].device)
+            base = self.buf.data_ptr()
+            rec = np.zeros((len(plan), 11), np.int64)
+            self.entries = {}
+            for i, (w, t, taps, cin, cout, cin_p, cout_p, o_f, o_b) in enumerate(plan):
+                n = taps * cin_p * cout_p
+                rec[i] = [w.data_ptr(), base + 4 * o_f, base + 4 * o_b, taps, int(t), cin, cout, cin_p, cout_p, 0, 0]
+                self.entries[id(w)] = (w.data_ptr(), self.buf[o_f:o_f + n].view(taps, cout_p, cin_p), self.buf[o_b:o_b + n].view(taps, cin_p, cout_p))
+            self.descs = rec
+            self.key = key
+        _l.check(_l.load().urn_dense_weight_layouts(len(self.descs), self.descs.ctypes.data, _l.stream()), 'dense_weight_layouts')
+        self.valid = True
+
+    def get(self, weight):
+        e = self.entries.get(id(weight)) if self.valid else None
+        if e is None or e[0] != weight.data_ptr():
+            return None
+        return e[1], e[2]
+
+
+_WL = _WeightLayouts()
+
+
+def prepare_weights(convs):
+    if convs and convs[0][0].is_cuda:
+        _WL.prepare(convs)
+
+
+def invalidate_weights():
+    """the prepared layouts describe the parameters as they were at prepare_weights(): callers that change a weight between a
+    forward pass and another use of these Functions without a new forward (tests) drop them"""
+    _WL.valid = False
+
+
 def _pad16(t, dim):
     n = t.shape[dim]
     padn = (-n) % 16
@@ -210,8 +268,13 @@ class DenseConvFunction(torch.autograd.Function):
         Out, fwd, bwd, padinfo = conv_geoms(spatial, k, stride, pad_lo, pad_hi)
         # weights as [tap][cout][cin], channel counts zero-padded to multiples of 16 (the 1-channel input conv, the
         # num_class-channel output conv)
-        wt = weight.reshape(cout, cin, -1).permute(2, 0, 1).contiguous()
-        wt = _pad16(_pad16(wt, 1), 2)
+        prepared = _WL.get(weight)
+        if prepared is not None:
+            wt, wb = prepared
+        else:
+            wt = weight.reshape(cout, cin, -1).permute(2, 0, 1).contiguous()
+            wt = _pad16(_pad16(wt, 1), 2)
+            wb = None
         xin = _pad16(rows, 1)
         cin_p, cout_p = wt.shape[2], wt.shape[1]
         bias_p = None if bias is None else _pad16(bias.contiguous(), 0)
@@ -224,6 +287,7 @@ class DenseConvFunction(torch.autograd.Function):
         _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, fwd, stats, xfp)
         ctx.save_for_backward(xin, weight)
         ctx.xfp = xfp
+        ctx.wb = wb                # the input gradient's operand, written by prepare_weights() together with wt (or None)
         ctx.meta = (B, tuple(spatial), stride, Out, bwd, padinfo, cin, cout, cin_p, cout_p, bias is not None)
         ctx.bias_grad = bias_grad
         ctx.out_spatial = tuple(Out[3 - nd:])
@@ -238,8 +302,10 @@ class DenseConvFunction(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dxp[pp][ci] = sum dy[o][co] W[co][ci][t]: weights as [tap][ci][co]
-            wb = weight.reshape(cout, cin, -1).permute(2, 1, 0).contiguous()
-            wb = _pad16(_pad16(wb, 1), 2)
+            wb = ctx.wb
+            if wb is None:
+                wb = weight.reshape(cout, cin, -1).permute(2, 1, 0).contiguous()
+                wb = _pad16(_pad16(wb, 1), 2)
             n_p = B * Pd[0] * Pd[1] * Pd[2]
             full = stride == 1 or len(bwd) == 2 ** len(spatial)      # every padded position is written by some launch
             dxp = (torch.empty if full else torch.zeros)((n_p, cin_p), dtype=torch.float32, device=dy.device)
@@ -295,8 +361,13 @@ class DenseConvTransposeFunction(torch.autograd.Function):
         nd = len(spatial)
         cin, cout = weight.shape[0], weight.shape[1]
         Out, fwd, bwd = convT_geoms(spatial)
-        wt = weight.reshape(cin, cout, -1).permute(2, 1, 0).contiguous()            # [tap][cout][cin]
-        wt = _pad16(_pad16(wt, 1), 2)
+        prepared = _WL.get(weight)
+        if prepared is not None:
+            wt, wb = prepared
+        else:
+            wt = weight.reshape(cin, cout, -1).permute(2, 1, 0).contiguous()            # [tap][cout][cin]
+            wt = _pad16(_pad16(wt, 1), 2)
+            wb = None
         xin = _pad16(rows, 1)
         cin_p, cout_p = wt.shape[2], wt.shape[1]
         bias_p = None if bias is None else _pad16(bias.contiguous(), 0)
@@ -304,6 +375,7 @@ class DenseConvTransposeFunction(torch.autograd.Function):
         for g in fwd:
             _launch(xin, cin_p, cin_p, wt, bias_p, y, cout_p, cout_p, B, g, stats)
         ctx.save_for_backward(xin, weight)
+        ctx.wb = wb
         ctx.meta = (B, tuple(spatial), Out, bwd, cin, cout, cin_p, cout_p, bias is not None)
         ctx.bias_grad = bias_grad
         ctx.out_spatial = tuple(Out[3 - nd:])
@@ -319,8 +391,10 @@ class DenseConvTransposeFunction(torch.autograd.Function):
         dx = dw = db = None
         In = _dims3(spatial)
         if ctx.needs_input_grad[0]:
-            wb = weight.reshape(cin, cout, -1).permute(2, 0, 1).contiguous()          # [tap][cin][cout]: kernel cout = cin
-            wb = _pad16(_pad16(wb, 1), 2)
+            wb = ctx.wb
+            if wb is None:
+                wb = weight.reshape(cin, cout, -1).permute(2, 0, 1).contiguous()          # [tap][cin][cout]: kernel cout = cin
+                wb = _pad16(_pad16(wb, 1), 2)
             dxf = torch.empty((B * In[0] * In[1] * In[2], cin_p), dtype=torch.float32, device=dy.device)
             _launch(dy, cout_p, cout_p, wb, None, dxf, cin_p, cin_p, B, bwd)
             dx = dxf[:, :cin].contiguous() if cin_p != cin else dxf

@@ -126,6 +126,7 @@ SIGNATURES = {
     'urn_dense_dw_scratch_bytes': (c_i64, [c_int, c_void_p, c_void_p, c_int, c_int]),
     'urn_dense_dw': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    'urn_dense_weight_layouts': (c_int, [c_int, c_void_p, c_void_p]),
     'urn_dense_fold': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'urn_dense_bn_act_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_int,
                                      c_void_p]),

@@ -130,6 +130,12 @@ class UResNet(nn.Module):
                 raise RuntimeError('dense kernels: MFMA operand precision fp32 or bf16 (got %s)' % prec)
             _dc.set_precision(prec)
             _dc.pool_begin(input.device)        # one memset for the step's fp64 accumulation slabs
+            # both kernel layouts of every convolution's weight in one launch (the parameters as they are NOW: the backward
+            # pass of this forward reads the input-gradient layouts written here)
+            if getattr(self, '_conv_list', None) is None:
+                self._conv_list = [(mod.weight, isinstance(mod, (nn.ConvTranspose2d, nn.ConvTranspose3d)))
+                                   for mod in self.modules() if isinstance(mod, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d))]
+            _dc.prepare_weights(self._conv_list)
         conv_feature_map = {}
         net = _conv_bn(self.conv1, input, relu=True)
         conv_feature_map[net.size()[1]] = net            # skip links keyed by channel count (reference :210,214)
