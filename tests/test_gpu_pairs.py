@@ -333,47 +333,6 @@ def test_pairs_reduced_precision_on_16bit_fragments(dev, cin, cout, prec, tol):
     assert not torch.equal(y_pairs, y_tile)
 
 
-@pytest.mark.parametrize('cin,cout', [(16, 16), (32, 32), (48, 48), (64, 64), (32, 16)])
-def test_pairs_ring_variant_gives_the_same_bits(dev, cin, cout):
-    """urn_set_option("pairs_deep", bits): the ring variant of the pair-list kernel (three rotating register sets for rows and
-    weight blocks, requests two blocks ahead, steps past the end of a wave's share on clamped pair words into the trash row)
-    multiplies the same operands in the same order as the default loop -- identical results, with and without the folded
-    input BatchNorm"""
-    from uresnet_pytorch_amd import lib as _l, sparse_ops as so
-    L = _l.load()
-    S = 32
-    c, f = cloud(17, S, 2500, 2)
-    geo = so.SparseGeometry(torch.from_numpy(c).to(dev), S, 1)
-    n = geo.n[0]
-    g = torch.Generator(device='cpu').manual_seed(cin * 3 + cout)
-    x = torch.randn(n, cin, generator=g).to(dev)
-    wt = (torch.randn(27, cout, cin, generator=g) * 0.1).to(dev)
-    sc = (torch.rand(cin, generator=g) + 0.5).to(dev); sh = (torch.randn(cin, generator=g) * 0.1).to(dev)
-    wf = torch.empty_like(wt)
-    _l.check(L.urn_weight_fragments(wt.data_ptr(), 27, cout, cin, wf.data_ptr(), _l.stream()), 'weight_fragments')
-    pl = geo.pairs['nbr'][0]
-    outs = {}
-    try:
-        L.urn_set_option(b'pairs_v3', 0)     # (the strip variant takes precedence over the ring)
-        for bits in (0, 30):
-            L.urn_set_option(b'pairs_deep', bits)
-            for xf in (False, True):
-                y = torch.empty(n, cout, device=dev)
-                a = _l.GConvArgs()
-                a.x = x.data_ptr(); a.wt = wt.data_ptr(); a.tbl = geo.nbr[0].data_ptr(); a.ld = geo.ld; a.K = 27; a.flip = 0; a.n_out = n
-                a.cin = cin; a.cout = cout; a.y = y.data_ptr(); a.pairs = pl[0].data_ptr(); a.pairs_tile = pl[1]; a.wt_frag = wf.data_ptr()
-                if xf:
-                    a.xf_scale = sc.data_ptr(); a.xf_shift = sh.data_ptr()
-                _l.check(L.urn_gconv_fwd_ex(ctypes.byref(a), None, _l.stream()), 'gconv_fwd_ex')
-                outs[(bits, xf)] = y
-    finally:
-        L.urn_set_option(b'pairs_deep', 0)
-        L.urn_set_option(b'pairs_v3', 0x17E)
-    for xf in (False, True):
-        assert torch.equal(outs[(0, xf)], outs[(30, xf)]), (cin, cout, xf)
-    assert not torch.equal(outs[(0, False)], outs[(0, True)])
-
-
 @pytest.mark.parametrize('cin,cout', [(16, 16), (32, 32), (48, 48), (64, 64), (80, 80), (96, 48), (128, 64), (32, 16), (16, 32)])
 def test_pairs_strip_variant(dev, cin, cout):
     """urn_set_option("pairs_v3", bits), the default loop of the pair-list kernel for one-chunk inputs: the pair words of a wave's

@@ -69,7 +69,6 @@ for kind, lv, ci, co in shapes:
     use_frag = mode in ('sweep', 'abl', 'v3')
     for name, nc, G, *rest in variants:
         L.urn_set_option(b'pairs_cbg', rest[0] if rest else 0)
-        L.urn_set_option(b'pairs_deep', rest[1] if len(rest) > 1 else 1)
         L.urn_set_option(b'pairs_v3', rest[2] if len(rest) > 2 else 0x17E)
         L.urn_set_option(b'gconv_dbg', -nc if nc < 0 else 0)
         L.urn_set_option(b'pairs_nc', max(nc, 0)); L.urn_set_option(b'pairs_split', G)

@@ -310,7 +310,7 @@ struct Pick { int mb, nb; };
 int g_opt_precision = 0;   // default MFMA operand precision of the gather convolutions: 0 fp32, 1 bf16, 2 fp16
 extern int g_net_skip_dw;
 extern int g_dw_pairs;
-extern int g_pairs_deep, g_pairs_v3;
+extern int g_pairs_v3;
 extern int g_dw_2stage;
 extern long long *g_dense_stamps;
 extern int g_net_wfrag, g_net_side2;
@@ -350,7 +350,6 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "pairs_wgs")) { g_pairs_wgs = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_waves_fwd")) { g_pairs_waves_fwd = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_wgs16")) { g_pairs_wgs16 = (int)value; return URN_OK; }
-    if (!strcmp(key, "pairs_deep")) { g_pairs_deep = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_v3")) { g_pairs_v3 = (int)value; return URN_OK; }
     if (!strcmp(key, "dw_pairs")) { g_dw_pairs = value != 0; return URN_OK; }
     if (!strcmp(key, "net_dbg_skip_dw")) { g_net_skip_dw = value != 0; return URN_OK; }

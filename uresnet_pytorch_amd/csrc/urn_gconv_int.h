@@ -40,7 +40,7 @@ struct GArgs {
     // compacted rule lists (urn_gconv_pairs.hip): list of the table (NULL with p_tile != 0 = identity table of a 1x1 conv),
     // rows per tile (64 / 128), split of a tile's block list over waves, columns per workgroup
     const int *pairs;
-    int p_tile, p_split, p_cw, p_deep;   // p_deep: loop variant, 0 = block loop with per-block index loads, 1 = ring (three register sets), 2 = strip (pair words of the share in LDS)
+    int p_tile, p_split, p_cw, p_deep;   // p_deep: loop variant, 0 = block loop with per-block index loads (several channel chunks, or no fragment-ordered weights), 2 = strip (pair words of the tile in LDS; default)
     int p_strip;   // variant 2: blocks per wave-private strip (a multiple of 16)
     long long *stamps;   // diagnostics (urn_set_option "gconv_stamp_ptr"): 8 s_memtime values per wave of the pair-list kernel
     int dbg;   // timing-only ablation mask (urn_set_option "gconv_dbg"): 1 no MFMA, 2 no A fetch, 4 no B fetch, 8 no barrier, 16 no offsets

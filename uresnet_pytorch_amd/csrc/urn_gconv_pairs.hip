@@ -31,7 +31,6 @@
 #else
 #define URN_DBG(g, bits) 0
 #endif
-#define URN_PAIRS_IDXB 24   // blocks per chunk of the wave-private pair-word strip in LDS (DEEP variants)
 
 // ------------------------------------------------------------------------------------------------ list builder
 #define URN_PAIRS_MAX_TABLES 16
@@ -163,7 +162,7 @@ __device__ __forceinline__ f32x4 pairs_mfma16(urn_s16x4 a, urn_s16x4 b, f32x4 c)
 // (register estimate of the loop: rows as loaded + operand registers 8 KC, weight fragments 4 KC NC)
 #define URN_PAIRS_REGS(KC, NC, PREC) ((KC) * ((NC) + 2) * 4)
 template <int KC, int NC, int XF, int DEEP, int PREC = 0>
-__global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) <= 64 ? 1024 : 512, (KC <= 2 && NC == 1 && DEEP != 1) ? 5 : 1) void k_gconv_pairs(GArgs g)
+__global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (KC <= 2 && NC == 1) ? 5 : 1) void k_gconv_pairs(GArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // diagnostics, compiled only with -DURN_PAIRS_STAMP (make CXXFLAGS+=...): s_memtime at the phase boundaries of every wave
@@ -206,8 +205,6 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
 
     const bool ident = g.pairs == nullptr;   // 1x1 convolution on the identity table: blocks of 16 consecutive rows
     const int *hdr = ident ? nullptr : g.pairs + (long)tile * urn_pairs_words(K, T);
-    const int *blk_t = hdr + URN_PAIRS_HDR;
-    const int *blk_p = blk_t + urn_pairs_tpad(K, T);
     const int nblk = ident ? (rows_here + 15) >> 4 : hdr[0];
     // ADDRESSING of the block loop.  With 64-bit pointers every gathered row cost two v_mad_u64_u32, a v_lshl_add_u64 and moves,
     // every pair word and weight block the same again: ~130 vector instructions per block of 8 MFMAs at 32 -> 32, the loop was
@@ -395,7 +392,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
                     w[j][c] = __builtin_bit_cast(urn_s16x4, __builtin_amdgcn_raw_buffer_load_b64(rs_w, lane * 8, so + (c * kbn + j) * 512, 0));
             return;
         } else
-        if (DEEP != 0 || g.wfrag) {   // (the ring variants are launched with fragments only: no branch around these requests)
+        if (DEEP != 0 || g.wfrag) {   // (the strip variant is launched with fragments only: no branch around these requests)
             const int so = ((o * (cout / 16) + cb0) * kbn + ch * KC) * 1024;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
@@ -412,76 +409,6 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) * (DEEP == 1 ? 3 : 1) 
                 for (int j = 0; j < KC; ++j) w[j][c] = *(const f32x4 *)(src + (long)(16 * c) * cin + 16 * j);
         }
     };
-
-    // (DEEP is a template parameter: the rotating sets cost registers in every instantiation that contains them)
-    if constexpr (DEEP == 1) {
-        // RING variant (one channel chunk, cin = 16 KC; launcher: bit KC of `pairs_deep`).  The block loop is a latency chain per
-        // wave: a step is ~0.1 us of MFMAs between a request and the ~0.7 us until it is served, and a step cannot start without
-        // the weight block of its offset.  Three register sets for rows AND weight blocks rotate: step b multiplies set b % 3 and
-        // requests block b + 2 into set (b + 2) % 3 -- every request unconditional and in straight-line code (no branch around a
-        // load: hipcc then counts them, s_waitcnt vmcnt(N) leaves the two younger blocks in flight), unrolled by three so that
-        // no set is ever copied.  Steps past the end of the wave's share run on clamped pair words into the trash row.
-        // The pair words of the share are first copied into a wave-private LDS strip (chunks of IDXB blocks).
-        if (b0 < b1) {
-            f32x4 A0[KC], A1[KC], A2[KC];
-            wfrag_t W0[KC][NC], W1[KC][NC], W2[KC][NC];
-            int *my_idx = (int *)(s_p + 2 * (long)G * cw) + (long)wave * (URN_PAIRS_IDXB * 17);
-            // one block: slab rows of pair word pv from (use, wuse); rows and weight block of the block two ahead into (ld, wld)
-            auto step = [&](f32x4 (&use)[KC], wfrag_t (&wuse)[KC][NC], f32x4 (&ld)[KC], wfrag_t (&wld)[KC][NC], int pv, int tv_ld, int pl_ld) {
-                const int t_l = __builtin_amdgcn_readfirstlane(tv_ld);
-                float *dptr = slab + (long)((unsigned)pv >> 24) * LDW + 4 * q;
-                f32x4 old[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) old[c] = *(const f32x4 *)(dptr + 16 * c);
-                load_w(wld, t_l, 0);
-                load_a(ld, pl_ld, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                wfrag_t opn[KC];
-                ready(use, opn, 0);
-                f32x4 acc[NC], acc2[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-                if constexpr (PREC == 0) {
-#pragma unroll
-                    for (int j = 0; j < KC; ++j)
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                            for (int c = 0; c < NC; ++c) {
-                                if (tt & 1) acc2[c] = MFMA16(wuse[j][c][tt], opn[j][tt], acc2[c]);
-                                else acc[c] = MFMA16(wuse[j][c][tt], opn[j][tt], acc[c]);
-                            }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < KC; ++j)
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            if (j & 1) acc2[c] = pairs_mfma16<PREC>(wuse[j][c], opn[j], acc2[c]);
-                            else acc[c] = pairs_mfma16<PREC>(wuse[j][c], opn[j], acc[c]);
-                        }
-                }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = old[c] + (acc[c] + acc2[c]);
-            };
-            for (int c0 = b0; c0 < b1; c0 += URN_PAIRS_IDXB) {
-                const int c1 = c0 + URN_PAIRS_IDXB < b1 ? c0 + URN_PAIRS_IDXB : b1, nbk = c1 - c0;
-                for (int i = lane; i < nbk * 16; i += 64) my_idx[i] = blk_p[(long)c0 * 16 + i];
-                for (int i = lane; i < nbk; i += 64) my_idx[URN_PAIRS_IDXB * 16 + i] = blk_t[c0 + i];
-                auto PV = [&](int b) { const int w = my_idx[((b < c1 ? b : c1 - 1) - c0) * 16 + r]; return b < c1 ? w : (T << 24); };
-                auto PL = [&](int b) { return my_idx[((b < c1 ? b : c1 - 1) - c0) * 16 + gp]; };   // the lane's gather pair
-                auto TV = [&](int b) { return my_idx[URN_PAIRS_IDXB * 16 + ((b < c1 ? b : c1 - 1) - c0)]; };
-                load_w(W0, __builtin_amdgcn_readfirstlane(TV(c0)), 0);
-                load_a(A0, PL(c0), 0);
-                load_w(W1, __builtin_amdgcn_readfirstlane(TV(c0 + 1)), 0);
-                load_a(A1, PL(c0 + 1), 0);
-                for (int b = c0; b < c1; b += 3) {
-                    step(A0, W0, A2, W2, PV(b), TV(b + 2), PL(b + 2));
-                    step(A1, W1, A0, W0, PV(b + 1), TV(b + 3), PL(b + 3));
-                    step(A2, W2, A1, W1, PV(b + 2), TV(b + 4), PL(b + 4));
-                }
-            }
-        }
-    }
 
     if constexpr (DEEP == 2) {
         // STRIP variant (one channel chunk: cin = 16 KC; launcher: bit KC of `pairs_v3`).  What a CU's vector-memory path can
@@ -786,7 +713,6 @@ int g_pairs_nc = 0;          // force the column blocks per wave (urn_set_option
 int g_pairs_split = 0;
 int g_pairs_split_kc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // force G for inputs of 16 KC channels (urn_set_option "pairs_split_kc<KC>"), 0 = automatic
 int g_pairs_wgs = 512;       // a workgroup takes several column groups only while the launch keeps this many workgroups ("pairs_wgs")
-int g_pairs_deep = 0;        // bit KC set: the RING variant (three rotating register sets for rows and weight blocks, two blocks in flight) for inputs of 16 KC channels, KC <= 4 (urn_set_option "pairs_deep").  Off: measured in the cfg3 step 2.690 ms without, 2.689 with it for KC 1, 2.70 for KC 1-2, 2.74 for KC 1-3, 2.86 for KC 1-4 -- with requests two blocks ahead (s_waitcnt vmcnt(8..9) in the ISA) the loop is no faster: it is not waiting for memory
 int g_pairs_v3 = 0x17E;       // bit KC set: the STRIP variant (pair words of a wave's share in LDS, weight block of the next offset requested with the next rows) for one-chunk inputs of 16 KC channels (urn_set_option "pairs_v3")
 int g_pairs_cbg = 0;          // most column groups per workgroup (urn_set_option "pairs_cbg"), 0 = as many as fit       // force G (urn_set_option "pairs_split"), 0 = automatic
 
@@ -798,14 +724,6 @@ static void launch_pairs2(const GArgs &a, dim3 grid, dim3 block, size_t lds, hip
         if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 2>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 2>), grid, block, lds, st, a);
         return;
-    }
-    // DEEP variants exist for one-chunk inputs of up to 48 channels and one column block per wave
-    if constexpr (KC <= 4 && NC == 1) {
-        if (a.p_deep == 1) {
-            if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 1>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 1>), grid, block, lds, st, a);
-            return;
-        }
     }
     if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 0>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 0, 0>), grid, block, lds, st, a);
@@ -840,8 +758,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     if (g_pairs_nc == 1 || (g_pairs_nc == 2 && nblk % 2 == 0 && (kc <= 6 || a.prec != 0)) || (g_pairs_nc == 4 && nblk % 4 == 0 && a.prec != 0)) nc = g_pairs_nc;
     const int cbg_all = nblk / nc;
     const bool strip = ((g_pairs_v3 >> kc) & 1) && a.cin == 16 * kc && a.pairs != nullptr && a.wfrag != nullptr && nc <= 2;
-    const bool deep = !strip && a.prec == 0 && ((g_pairs_deep >> kc) & 1) && a.cin == 16 * kc && nc == 1 && kc <= 4 && a.pairs != nullptr && a.wfrag != nullptr;
-    const int maxw = URN_PAIRS_REGS(kc, nc, a.prec) * (deep ? 3 : 1) <= 64 ? 16 : 8;   // waves per workgroup (register budget, see __launch_bounds__)
+    const int maxw = URN_PAIRS_REGS(kc, nc, a.prec) <= 64 ? 16 : 8;   // waves per workgroup (register budget, see __launch_bounds__)
     // Workgroups first: the deep levels have few tiles (103 of 64 rows at level 3 of cfg3), and one workgroup per tile left
     // most of the 256 CUs idle (measured 56 -> 15 us at level 4, 80 -> 80, with one column group per workgroup): give a
     // workgroup fewer column groups (its rows are then gathered by several workgroups -- L2 hits) until the launch has
@@ -855,8 +772,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     auto strip_blocks = [&](int) { return (maxb + 15) & ~15; };   // ONE strip per workgroup: the longest list a tile can have, in whole 16-block fills
     auto lds_bytes = [&](int G) {
         size_t w = (size_t)2 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
-        return w * 4 + (size_t)2 * G * cw * 8 + (deep ? (size_t)cbg * G * URN_PAIRS_IDXB * 17 * 4 : 0) +
-               (strip ? (size_t)strip_blocks(G) * 17 * 4 + 16 : 0);
+        return w * 4 + (size_t)2 * G * cw * 8 + (strip ? (size_t)strip_blocks(G) * 17 * 4 + 16 : 0);
     };
     int G = 1;
     const int want_waves = (a.epi != 2 && g_pairs_waves_fwd > 0) ? g_pairs_waves_fwd : g_pairs_waves;
@@ -871,7 +787,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
         gy = cbg_all / cbg; cw = 16 * nc * cbg;
     }
     if (lds_bytes(G) > 65536) return 0;
-    a.p_split = G; a.p_cw = cw; a.p_deep = strip ? 2 : (deep ? 1 : 0); a.p_strip = strip ? strip_blocks(G) : 0;
+    a.p_split = G; a.p_cw = cw; a.p_deep = strip ? 2 : 0; a.p_strip = strip ? strip_blocks(G) : 0;
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
     const size_t lds = lds_bytes(G);
 #define URN_PL(KCv, NCv) if (kc == KCv && nc == NCv) { launch_pairs2<KCv, NCv>(a, grid, block, lds, st); return (int)ntiles; }
