@@ -11,6 +11,8 @@ import torch
 from uresnet_pytorch_amd.models import DenseUResNet, DenseSegmentationLoss
 from uresnet_pytorch_amd.models.uresnet_dense import padding
 
+import relu_hooks
+
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 TOL = 1e-5
 
@@ -73,21 +75,15 @@ def test_dense_cpu_route_gradients_with_reference_masks(name):
     def free_relu(pre):
         own.append(pre.detach() > 0); pres.append(pre.detach().clone())
         return torch.relu(pre)
-    D.RELU_OVERRIDE = free_relu
-    try:
+    with relu_hooks.cpu_relu(free_relu):
         net(x)
-    finally:
-        D.RELU_OVERRIDE = None
     flips, total, worst = mask_flips(own, ref_m, pres)
     assert flips <= max(4, int(2e-6 * total)) and worst < 1e-5, (flips, total, worst)
     it = iter(ref_m)
-    D.RELU_OVERRIDE = lambda pre: pre * next(it).to(pre.dtype)
-    try:
+    with relu_hooks.cpu_relu(lambda pre: pre * next(it).to(pre.dtype)):
         logits = net(x)
         loss, acc = DenseSegmentationLoss(flags)(list(logits), list(x), list(lab), None)
         net.zero_grad(); loss.backward()
-    finally:
-        D.RELU_OVERRIDE = None
     assert next(it, None) is None
     assert rel(logits.detach().numpy(), g['logits']) < TOL
     assert abs(loss.item() - float(g['loss'])) < TOL * abs(float(g['loss']))
@@ -138,11 +134,8 @@ def test_dense_model_gpu_route_matches_reference_golden(name):
     g, flags, net = load(name, dev)
     x = torch.from_numpy(g['input']).to(dev); lab = torch.from_numpy(g['label']).to(dev)
     masks = []
-    D.RELU_RECORD = lambda y: masks.append((y > 0).cpu())
-    try:
+    with relu_hooks.gpu_relu_record(lambda y: masks.append((y > 0).cpu())):
         logits = net(x)
-    finally:
-        D.RELU_RECORD = None
     assert rel(logits.detach().cpu().numpy(), g['logits']) < 2 * TOL
     crit = DenseSegmentationLoss(flags)
     loss, acc = crit(list(logits), list(x), list(lab), None)
@@ -171,12 +164,9 @@ def run_pinned(cpu, gpu, x, lab, crit, dev):
     worst parameter-gradient error (norm-wise, against max(|ref|, 1e-4 of the largest gradient norm)) and its key."""
     from uresnet_pytorch_amd import dense_ops as D
     masks = []
-    D.RELU_RECORD = lambda y: masks.append((y > 0).cpu())
-    try:
+    with relu_hooks.gpu_relu_record(lambda y: masks.append((y > 0).cpu())):
         xg, lg = x.to(dev), lab.to(dev)
         out_g = gpu(xg); loss_g, acc_g = crit(list(out_g), list(xg), list(lg), None); loss_g.backward()
-    finally:
-        D.RELU_RECORD = None
     # the CPU route on its OWN branches first: forward, loss and accuracy are compared unpinned, and the GPU's masks may
     # differ from the CPU route's own only in a handful of entries whose pre-activation is within rounding of zero (a wrong
     # scale / shift on the GPU side would flip thousands and must not be copied into the reference run unnoticed)
@@ -185,12 +175,8 @@ def run_pinned(cpu, gpu, x, lab, crit, dev):
     def free_relu(pre):
         own.append(pre.detach() > 0); pres.append(pre.detach().clone())
         return torch.relu(pre)
-    D.RELU_OVERRIDE = free_relu
-    try:
-        with torch.no_grad():
-            out_f = cpu(x); loss_f, acc_f = crit(list(out_f), list(x), list(lab), None)
-    finally:
-        D.RELU_OVERRIDE = None
+    with relu_hooks.cpu_relu(free_relu), torch.no_grad():
+        out_f = cpu(x); loss_f, acc_f = crit(list(out_f), list(x), list(lab), None)
     flips, total, worst_pre = mask_flips(masks, own, pres)
     print('pinned run: %d of %d ReLU branches differ from the CPU route\'s own (|pre|/rms <= %.1e)' % (flips, total, worst_pre))
     assert flips <= max(8, int(1e-5 * total)) and worst_pre < 1e-4, (flips, total, worst_pre)
@@ -198,11 +184,8 @@ def run_pinned(cpu, gpu, x, lab, crit, dev):
     assert abs(loss_g.item() - loss_f.item()) < 2 * TOL * abs(loss_f.item())
     assert abs(float(acc_g) - float(acc_f)) < 1e-4
     it = iter(masks)
-    D.RELU_OVERRIDE = lambda pre: pre * next(it).to(pre.dtype)
-    try:
+    with relu_hooks.cpu_relu(lambda pre: pre * next(it).to(pre.dtype)):
         out_c = cpu(x); loss_c, acc_c = crit(list(out_c), list(x), list(lab), None); loss_c.backward()
-    finally:
-        D.RELU_OVERRIDE = None
     assert next(it, None) is None, 'the two routes made a different number of ReLU calls'
     assert rel(out_g.detach().cpu().numpy(), out_c.detach().numpy()) < 2 * TOL
     assert abs(loss_g.item() - loss_c.item()) < 2 * TOL * abs(loss_c.item())
