@@ -127,7 +127,7 @@ def test_padding_table_matches_reference():
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['dense_cfg1_2d', 'dense_mini_3d'])
 def test_dense_model_gpu_route_matches_reference_golden(name):
-    """Same golden vectors through the GPU route (dense_hip.py: gather-conv + BN HIP kernels via the C ABI)."""
+    """Same golden vectors through the GPU route (dense_hip.py: dense implicit-GEMM convolution + BatchNorm row kernels via the C ABI)."""
     assert torch.cuda.is_available()
     dev = torch.device('cuda:0')
     from uresnet_pytorch_amd import dense_ops as D
@@ -230,7 +230,7 @@ def test_dense_gpu_gradients_with_pinned_masks(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize('S,uns,B', [(32, 3, 2), (64, 4, 1)])
 def test_dense_gpu_route_mfma_channels_vs_cpu_route(S, uns, B):
-    """BASELINE configs[1] topology (-dd 3 -uf 16: channel counts 16..256, the MFMA gather-conv kernels incl. channel
+    """BASELINE configs[1] topology (-dd 3 -uf 16: channel counts 16..256, the MFMA implicit-GEMM kernels incl. channel
     chunking) at reduced spatial size: GPU route against the CPU route of the same module, which the golden vectors
     above pin to the reference.  Forward/loss 2e-5; every parameter gradient 2e-5 with the ReLU masks pinned (run_pinned)."""
     from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob

@@ -9,6 +9,12 @@
 // Arithmetic, determinism, epilogues and the partial-slab layout (one row per workgroup) are unchanged.
 #include "urn_common.h"
 #include "urn_gconv_int.h"
+// timing-only ablation switches exist in -DURN_DIAG builds only (the product kernels carry no diagnostic branch)
+#ifdef URN_DIAG
+#define URN_TILE_DBG(g, bits) ((g).dbg & (bits))
+#else
+#define URN_TILE_DBG(g, bits) 0
+#endif
 #include <type_traits>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
     // row tiles would land on 8 different L2s and every XCD would fetch (nearly) the whole input.  Give XCD x a
     // contiguous range of tiles instead: rows that are neighbours in space are mostly neighbours in the site order.
     unsigned tile_x = blockIdx.x;
-    if (!(g.dbg & 64) && gridDim.y == 1) {
+    if (!URN_TILE_DBG(g, 64) && gridDim.y == 1) {
         const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
         tile_x = xcd * xq + (xcd < xr ? xcd : xr) + slot;
     }
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(64 * RB * CB) void k_gconv_tile(GArgs g)
 #pragma unroll
     for (int i = 0; i < RB; ++i) m |= s_mask[i];
     const unsigned my_mask = s_mask[rb];
-    if (g.dbg & 16) m = 0u;
+    if (URN_TILE_DBG(g, 16)) m = 0u;
 
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
     // operands of the epilogue (residual, BatchNorm input of the backward reduce) are requested now: their round trip
@@ -580,6 +586,7 @@ int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
     if (g_tile_rb > 0) rb = g_tile_rb;
     if (g_tile_cb > 0 && nblk % g_tile_cb == 0) cb = g_tile_cb;
     if (!lds_ok(rb, cb)) return 0;
+#ifdef URN_DIAG   // stamp builds and timing-only ablations of two shapes: diagnostic library only (tools/build_diag_lib.sh)
     if ((a.dbg & 32) && KS == 4 && a.cout == 64) {   // diagnostic stamp build of one shape
         if constexpr (KS == 4) {
             const long bx = (n_out + 31) / 32;
@@ -607,6 +614,7 @@ int launch_tile_ks(const GArgs &a, long n_out, int nblk, hipStream_t st)
 #undef URN_ABL
         }
     }
+#endif
 #define URN_TL(RBv, CBv) if (rb == RBv && cb == CBv) return launch_tile2<KS, RBv, CBv>(a, n_out, st);
     URN_TL(1, 1) URN_TL(2, 1) URN_TL(4, 1) URN_TL(1, 2) URN_TL(2, 2) URN_TL(4, 2) URN_TL(1, 3) URN_TL(2, 3) URN_TL(4, 3)
     URN_TL(1, 4) URN_TL(2, 4) URN_TL(4, 4) URN_TL(1, 5) URN_TL(2, 5)
