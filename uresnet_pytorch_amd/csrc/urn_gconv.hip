@@ -227,8 +227,21 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
-    const int o = blockIdx.y;
-    const int ci_tile = blockIdx.z % n_ci_tiles, co_tile = blockIdx.z / n_ci_tiles;
+    // XCD-aware work assignment (workgroups are dealt round-robin to the 8 XCDs in launch order, each with its own L2): XCD x
+    // takes a contiguous range of the (row chunk, offset, channel tile) items, chunk-major -- the K offsets and the channel
+    // tiles of a row chunk read the same dy rows and neighbouring x rows, now through one L2 instead of up to eight
+    unsigned chunk_id, o_id, z_id;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+        const unsigned lin = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+        const unsigned xq = total >> 3, xr = total & 7u, xcd = lin & 7u, slot = lin >> 3;
+        const unsigned v = xcd * xq + (xcd < xr ? xcd : xr) + slot;
+        chunk_id = v / (gy * gz);
+        const unsigned rem = v - chunk_id * (gy * gz);
+        z_id = rem / gy; o_id = rem - z_id * gy;
+    }
+    const int o = (int)o_id;
+    const int ci_tile = (int)z_id % n_ci_tiles, co_tile = (int)z_id / n_ci_tiles;
     const int ci0 = ci_tile * DW_MAXI * 16, co0 = co_tile * DW_MAXN * 16;
     const int ci_w = min(DW_MAXI * 16, cin - ci0), co_w = min(DW_MAXN * 16, cout - co0);
     const int mi_n = ci_w / 16, ni_n = co_w / 16, nblk = mi_n * ni_n;
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
     }
     f32x4 ra[2][2], rb[2][3];   // register ring: two batches in flight
 
-    const long row_begin = (long)blockIdx.x * chunk;
+    const long row_begin = (long)chunk_id * chunk;
     const long row_end = min(n_out, row_begin + chunk);
     for (long sub = row_begin; sub < row_end; sub += DW2_LIST) {
         // ---- phase A: compact the valid (in, out) pairs of up to 1024 rows, row order preserved ----
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
     // of a part is written by exactly one wave of the grid; k_dw2_reduce adds the parts in a fixed order (no atomics:
     // bitwise reproducible)
     const long wn = (long)gridDim.y * cin * cout;
-    float *dst = slab ? slab + ((long)blockIdx.x * WPB + (KT > 32 ? wave / nblk : 0)) * wn : dw;
+    float *dst = slab ? slab + ((long)chunk_id * WPB + (KT > 32 ? wave / nblk : 0)) * wn : dw;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         if (KT > 32 || wave + 4 * s < nblk) {   // split batches: every wave holds a partial of its block

@@ -182,7 +182,19 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     const int cw = g.p_cw;                         // columns of this workgroup (blockIdx.y selects the column range)
     const int CBG = cw / (16 * NC);
     const int cg = wave % CBG, gi = wave / CBG;
-    const int colw = blockIdx.y * cw;              // first column of the workgroup
+    // XCD-aware work assignment.  Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest, then y), and every
+    // XCD has its own L2: XCD x takes a contiguous range of the (tile, column group) items, tile-major -- the column groups of
+    // a tile gather the SAME rows and now do so through one L2, neighbouring tiles (whose rows overlap) likewise.  (Mapping the
+    // tiles alone, by blockIdx.x, put the column groups of a tile on different XCDs whenever the tile count is not a multiple
+    // of 8: every row of the deep levels was fetched by four or five L2s.)
+    unsigned tile, cgroup;
+    {
+        const unsigned gy = gridDim.y, total = gridDim.x * gy, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned xq = total >> 3, xr = total & 7u, xcd = lin & 7u, slot = lin >> 3;
+        const unsigned v = xcd * xq + (xcd < xr ? xcd : xr) + slot;
+        tile = v / gy; cgroup = v - tile * gy;
+    }
+    const int colw = (int)cgroup * cw;             // first column of the workgroup
     const int lcol0 = cg * 16 * NC;                // first column of the wave inside the workgroup's range
     const int col0 = colw + lcol0;
     const int LDW = cw + 4;                        // +4 floats: consecutive rows start 16 B apart in the bank row
@@ -193,12 +205,6 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     double *s_p = (double *)(s_slab + (((long)G * slab_words + 1) & ~1L));
 
     const long n_out = g.n_dev ? (long)*g.n_dev : g.n_cap;
-    // XCD-aware tile assignment (workgroups are dealt round-robin to the 8 XCDs): XCD x gets a contiguous range of tiles
-    unsigned tile = blockIdx.x;
-    {
-        const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        tile = xcd * xq + (xcd < xr ? xcd : xr) + slot;
-    }
     const long row0 = (long)tile * T;
     const int rows_here = (int)(n_out - row0 < (long)T ? n_out - row0 : (long)T);
     if (rows_here <= 0) return;   // workgroup-uniform
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     if constexpr (XF != 0) {
         if (g.xs_sums[0] != nullptr) {
             // statistics of the input rows accumulated by the producers: same arithmetic as k_bn_finalize_fwd_f
-            const bool keep = blockIdx.x == 0 && blockIdx.y == 0;
+            const bool keep = tile == 0 && cgroup == 0;
             const double inv_n = g.xs_n > 0 ? 1.0 / (double)g.xs_n : 0.0;
             for (int e = tid; e < cin; e += nthreads) {
                 const int sl = e >= g.xs_split ? 1 : 0;
