@@ -162,7 +162,7 @@ __device__ __forceinline__ f32x4 pairs_mfma16(urn_s16x4 a, urn_s16x4 b, f32x4 c)
 // (register estimate of the loop: rows as loaded + operand registers 8 KC, weight fragments 4 KC NC)
 #define URN_PAIRS_REGS(KC, NC, PREC) ((KC) * ((NC) + 2) * 4)
 template <int KC, int NC, int XF, int DEEP, int PREC = 0>
-__global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (KC <= 2 && NC == 1) ? 5 : 1) void k_gconv_pairs(GArgs g)
+__global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (KC <= 2 && NC == 1) ? (DEEP == 2 ? 4 : 5) : 1) void k_gconv_pairs(GArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // diagnostics, compiled only with -DURN_PAIRS_STAMP (make CXXFLAGS+=...): s_memtime at the phase boundaries of every wave
@@ -579,8 +579,6 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     }
     URN_STAMP(2);
     if (URN_DBG(g, 64)) return;
-    __syncthreads();
-    URN_STAMP(3);
 
     // epilogue: wave (cg, gi) finishes columns [col0, col0 + 16 NC) of the row groups gi, gi + G, ...  A lane owns FOUR
     // consecutive columns of a row (16-byte slab reads, residual / BatchNorm-input loads and stores; one float per lane made
@@ -595,10 +593,11 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
         emu = *(const f32x4 *)(g.e_mean + gcol); eis = *(const f32x4 *)(g.e_invstd + gcol);
     }
     // two row groups per pass: their residual / BatchNorm-input elements are requested together before the first is used
-    // (four per pass pushed every instantiation to the 128-VGPR cap: 2.82 -> 3.14 ms per step)
-#pragma unroll 1
-    for (int lr0 = gi * RPI + rl; lr0 < rows_here; lr0 += 2 * G * RPI) {
-        f32x4 rv[2], xg[2];
+    // (four per pass pushed every instantiation to the 128-VGPR cap: 2.82 -> 3.14 ms per step).  The FIRST pass' requests --
+    // with 64-row tiles the only pass -- go out in front of the barrier that ends the block loop: their round trip runs
+    // beside the wait for the workgroup's slowest wave (strip variant: it has the registers; the others load behind it)
+    f32x4 rv[2], xg[2];
+    auto request = [&](int lr0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int lr = lr0 + G * RPI * u;
@@ -606,6 +605,13 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
             rv[u] = (g.res && lr < rows_here) ? *(const f32x4 *)(g.res + row * cout + gcol) : (f32x4){0.f, 0.f, 0.f, 0.f};
             xg[u] = (g.epi == 2 && lr < rows_here) ? *(const f32x4 *)(g.e_x + row * cout + gcol) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    };
+    if constexpr (DEEP == 2) request(gi * RPI + rl);
+    __syncthreads();
+    URN_STAMP(3);
+#pragma unroll 1
+    for (int lr0 = gi * RPI + rl; lr0 < rows_here; lr0 += 2 * G * RPI) {
+        if (DEEP != 2 || lr0 != gi * RPI + rl) request(lr0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int lr = lr0 + G * RPI * u;
