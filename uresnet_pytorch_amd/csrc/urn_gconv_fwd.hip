@@ -313,7 +313,7 @@ extern int g_dw_pairs;
 extern int g_pairs_v3;
 extern int g_dw_2stage;
 extern long long *g_dense_stamps;
-extern int g_net_wfrag, g_net_side2, g_net_nin_side;
+extern int g_net_wfrag, g_net_side2;
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
 static long long *g_opt_stamps = nullptr;
@@ -355,7 +355,6 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "net_dbg_skip_dw")) { g_net_skip_dw = value != 0; return URN_OK; }
     if (!strcmp(key, "net_wfrag")) { g_net_wfrag = value != 0; return URN_OK; }
     if (!strcmp(key, "net_side2")) { g_net_side2 = value != 0; return URN_OK; }
-    if (!strcmp(key, "net_nin_side")) { g_net_nin_side = value != 0; return URN_OK; }
     if (!strcmp(key, "dw_2stage")) { g_dw_2stage = value != 0; return URN_OK; }
     if (!strcmp(key, "dwp_cap")) { g_dwp_cap = value >= 1 && value <= 5 ? (int)value : 2; return URN_OK; }
     if (!strcmp(key, "dwp_dbg")) { g_dwp_dbg = (int)value; return URN_OK; }

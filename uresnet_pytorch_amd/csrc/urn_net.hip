@@ -24,7 +24,6 @@ int g_net_skip_dw = 0;     // timing only (urn_set_option "net_dbg_skip_dw"): no
 int g_dw_pairs = 0;        // weight gradients on the two-stage pair-list kernel (bitwise reproducible) instead of the atomics kernel (urn_set_option "dw_pairs")
 int g_net_side_probe = 4;   // candidate side streams tried by an executor's first backward (urn_set_option "net_side_probe"; 0/1 = keep the first)
 int g_net_side_verbose = 0;
-int g_net_nin_side = 1;     // forward 1x1 shortcut convolutions on the (idle) side stream, beside the block's first convolution (urn_set_option "net_nin_side")
 int g_net_side2 = 1;        // weight gradients alternate between TWO side streams (urn_set_option "net_side2"): the backward pass is bound by the kernel time queued per stream (cfg3: 1.25 ms on the caller's stream, 1.30 ms of weight gradients); two side streams 2.65 -> 2.59 ms per step
 
 namespace {
@@ -648,27 +647,10 @@ struct urn_net {
         const int64_t n = geo.n[l];
         const int32_t *nbr = geo.nbr[l];
         const float *sc = x.x;
-        hipEvent_t nin_done = nullptr;
-        if (k.has_nin) {
-            // the 1x1 shortcut convolution depends on the block's input only and is needed by conv2's epilogue: on the side
-            // stream (idle during the forward pass) it runs beside conv1 instead of in front of it
-            hipStream_t keep = st;
-            const bool off = g_net_nin_side && side && events.size() >= 2 && live();
-            if (off) {
-                hipEvent_t e = events[ev_next++ % events.size()];
-                if (hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess) st = side;
-            }
-            sc = conv_f(k.nin, x, nullptr, nbr + 13 * geo.ld, n, nullptr, Cons()).x;
-            if (st != keep) {
-                nin_done = events[ev_next++ % events.size()];
-                check(hipEventRecord(nin_done, st) == hipSuccess ? URN_OK : URN_EHIP);
-                st = keep;
-            }
-        }
+        if (k.has_nin) sc = conv_f(k.nin, x, nullptr, nbr + 13 * geo.ld, n, nullptr, Cons()).x;
         Cons c_bn2; c_bn2.bn = &k.bn2;
         Act t = conv_f(k.conv1, x, &k.bn1, nbr, n, nullptr, c_bn2);
         k.bn2.x = t.x;
-        if (nin_done) check(hipStreamWaitEvent(st, nin_done, 0) == hipSuccess ? URN_OK : URN_EHIP);
         return conv_f(k.conv2, t, &k.bn2, nbr, n, sc, out0, out1);
     }
     // out: the BatchNorm that consumes this U's output
