@@ -447,6 +447,53 @@ def test_tail_kernels_and_fused_head(dev):
     assert rel(a.cpu().numpy(), bb.cpu().numpy()) < 1e-6
 
 
+def test_backward_callback_suffix_is_final(dev):
+    """urn_net_backward_cb (the hook of parallel.OverlappedAllReduce): when the call-back fires, every kernel that writes
+    [urn_net_suffix_offset, end) of the flat gradient buffer -- bottom level, decoder, last BatchNorm, head -- has been
+    enqueued, on the caller's stream or on a side stream ordered behind it.  A copy of the suffix issued from inside the
+    call-back BEHIND THE SIDE STREAM'S TAIL (where the collective goes) must therefore equal the suffix after the whole
+    backward pass bit for bit, the prefix must still change afterwards, and the offset must split the parameters where the
+    module tree says: everything from the deepest level's first block on."""
+    from uresnet_pytorch_amd import lib as _l, parallel
+    from uresnet_pytorch_amd.models import SparseSegmentationLoss
+    S, m, Lv, nc = 64, 16, 4, 5
+    blob = make_sparse_blob([21, 22], S, 4000)
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=m, URESNET_NUM_STRIDES=Lv, SPATIAL_SIZE=S, NUM_CLASS=nc)
+    P = orc.init_params(m, Lv, nc, seed=8)
+    net = make_model(flags, P, dev)
+    grads = parallel.FlatGradients(net)
+    data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
+    out = net(data)
+    loss, _ = SparseSegmentationLoss(flags)(out, [data], [label], None)
+    seen = {}
+
+    def hook(offset, side_ptr):
+        assert 'offset' not in seen, 'the call-back fired twice'
+        seen['offset'] = offset
+        assert side_ptr, 'the executor has a side stream on this box'
+        with torch.cuda.stream(torch.cuda.ExternalStream(side_ptr, device=dev)):
+            seen['suffix'] = grads.flat[offset:].clone()
+            seen['prefix'] = grads.flat[:offset].clone()
+    grads.zero()
+    net._executor.suffix_hook = hook
+    loss.backward()
+    net._executor.suffix_hook = None
+    torch.cuda.synchronize()
+    off = seen['offset']
+    assert torch.equal(seen['suffix'], grads.flat[off:]), 'something wrote into the suffix after the call-back'
+    assert not torch.equal(seen['prefix'], grads.flat[:off]), 'the encoder gradients were already complete?'
+    assert float(grads.flat[off:].abs().sum()) > 0
+    # where the offset falls in the module tree: the first parameter at or behind it belongs to the deepest level's first block
+    names = [k for k, _ in net.named_parameters()]
+    sizes = [p.numel() for _, p in net.named_parameters()]
+    starts = np.cumsum([0] + sizes[:-1])
+    i_first = int(np.searchsorted(starts, off))
+    assert int(starts[i_first]) == off
+    deepest = 'sparseModel.2' + '.4.1.2' * (Lv - 1) + '.'      # scn.UNet nests the next level at [4][1][2] of its Sequential
+    assert names[i_first].startswith(deepest) and not any(k.startswith(deepest) for k in names[:i_first]), names[i_first]
+    assert 0.3 < (grads.flat.numel() - off) / grads.flat.numel() < 0.9
+
+
 def test_fused_conv_pieces_vs_oracle(dev):
     """urn_gconv_fwd_ex: BatchNormReLU folded into the load, column statistics epilogue, BatchNorm-backward
     reduce epilogue; urn_gconv_bwd_dw_ex with the same input transform -- each against the oracle."""
