@@ -51,7 +51,8 @@ class UResNet(torch.nn.Module):
         # host time after that synchronisation is exposed in the step, host time before it is not
         ex.flatten(c.device, tail=(self.linear.weight, self.linear.bias))
         ex.prepare_weights()      # transposed / fragment-ordered weight copies on the side stream, beside the integer phase
-        geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels, defer_sync=True)
+        geo = so.SparseGeometry(c, inp.spatial_size, inp.num_levels, defer_sync=True, counts_hint=getattr(self, '_counts_hint', None))
+        self._last_geo = geo
         feats = so.input_features(geo, features)
         # the Linear head inside the executor (last BatchNormReLU + OutputLayer + Linear = one kernel) where it can be
         head = (self.linear.weight, self.linear.bias) if (self.fuse_head and ex.head_ok(self.linear.weight, self.linear.bias)) else None

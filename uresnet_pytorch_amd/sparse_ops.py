@@ -38,7 +38,7 @@ class SparseGeometry:
     (uresnet/models/uresnet_sparse.py:20-22).
     """
 
-    def __init__(self, coords, spatial_size, num_levels=1, defer_sync=False, per_level=False):
+    def __init__(self, coords, spatial_size, num_levels=1, defer_sync=False, per_level=False, counts_hint=None):
         """defer_sync=True: everything is enqueued but the level counts are not read back yet -- the caller does the
         rest of its host-side preparation (measured: host time after this synchronisation is exposed one to one in
         the step, host time before it is hidden behind the previous step's kernels) and then calls sync().
@@ -118,11 +118,13 @@ class SparseGeometry:
         # pair-list launches, so that when sync() returns the queue still holds those (~50 us of work on the cfg3 event)
         # and the host's first float-phase launches are not exposed (kernel trace before: 35 us idle at the blocking
         # copy + 34 us until the next launch arrived, per step).
-        self._n_host = _pinned_counts(nl)
-        self._n_gen = _PINNED_NEXT                 # (the ring slot is ours until 16 more geometries have been built)
-        self._n_host.copy_(self.counts[:nl], non_blocking=True)
-        self._n_event = torch.cuda.Event()
-        self._n_event.record(torch.cuda.current_stream(dev))
+        self._hint = None if counts_hint is None else [int(v) for v in counts_hint]
+        if self._hint is None:
+            self._n_host = _pinned_counts(nl)
+            self._n_gen = _PINNED_NEXT                 # (the ring slot is ours until 16 more geometries have been built)
+            self._n_host.copy_(self.counts[:nl], non_blocking=True)
+            self._n_event = torch.cuda.Event()
+            self._n_event.record(torch.cuda.current_stream(dev))
         # the 27-offset tables of every level in one launch (the multi-level entry points take up to MAX_MULTI levels)
         if nl <= MAX_MULTI:
             _l.check(L.urn_rulebook_subm_multi(nl, PA(*[c.data_ptr() for c in self.coords]), PA(*[cptr + 4 * l for l in range(nl)]),
@@ -179,6 +181,11 @@ class SparseGeometry:
 
     def sync(self):
         """the one host synchronisation of the integer phase: per-level site counts"""
+        if self.n is None and self._hint is not None:
+            # counts_hint: the caller knows the level counts (a captured step replays the geometry build of the event it was
+            # captured on): no read-back, nothing that synchronises
+            self.n = list(self._hint)
+            return self
         if self.n is None:
             if os.environ.get('URN_LATE_COUNTS'):     # A/B: the blocking copy at the end of the integer phase
                 self.n = self.counts.cpu().tolist()[:self.num_levels]
