@@ -461,14 +461,16 @@ int urn_net_backward_cb(urn_net *net, const float *d_rows, float *grads, void *s
 int urn_net_set_head(urn_net *net, const float *W, const float *b);
 /* the two kernels of the tail, for direct use (see urn_net_set_head): sums = accumulated statistics slab of x
  * ([slots][2][m] doubles) from which scale / shift (and mean / invstd / running statistics) are derived, or NULL = scale /
- * shift given; part = the slab the BatchNorm-backward sums are accumulated into (zeroed by the caller) */
+ * shift given; part = the slab the BatchNorm-backward sums are accumulated into (zeroed by the caller).  urn_tail_bwd ADDS
+ * the row gradients onto their sites (gsite (n_sites, m), zeroed by the caller) -- unless n_sites == n: every site then has
+ * exactly one row (row2site is onto the sites), the gradients are stored and gsite need not be zeroed.  m 16 or 32. */
 int urn_tail_fwd(const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W, const float *b,
                  const double *sums, int slots, int64_t n_sites, double eps, const float *gamma, const float *beta,
                  float *mean, float *invstd, float *scale, float *shift, float *running_mean, float *running_var,
                  double momentum, float *logits, void *stream);
 int urn_tail_bwd(const float *dlogits, const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W,
                  const float *scale, const float *shift, const float *mean, const float *invstd, float *gsite,
-                 float *dW, float *db, double *part, int slots, void *stream);
+                 int64_t n_sites, float *dW, float *db, double *part, int slots, void *stream);
 /* Side-stream probe: the ONE call of the executor that synchronises (`stream` and its candidate streams), therefore
  * explicit and optional -- once per handle at initialisation.  Keeps the fastest of a few candidate side streams for the
  * fork/join pattern of the backward pass against `stream` (see urn_net.hip: hardware-queue aliasing). */

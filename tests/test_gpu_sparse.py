@@ -400,22 +400,26 @@ def test_tail_kernels_and_fused_head(dev):
     assert rel(logits.cpu().numpy(), ref.cpu().numpy()) < 1e-6
     assert rel(mean.cpu().numpy(), mu.cpu().numpy()) < 1e-6 and rel(invstd.cpu().numpy(), isd.cpu().numpy()) < 1e-6
     assert rel(rm.cpu().numpy(), (0.1 * mu).cpu().numpy()) < 1e-6 and rel(rv.cpu().numpy(), (0.9 + 0.1 * var).cpu().numpy()) < 1e-6
-    dl = torch.randn(N, nc, generator=g).to(dev)
-    gsite = torch.zeros(n0, m, device=dev); dW = torch.zeros(nc, m, device=dev); db = torch.zeros(nc, device=dev)
-    part = torch.zeros(SLOTS, 2, m, dtype=torch.float64, device=dev)
-    _l.check(L.urn_tail_bwd(dl.data_ptr(), x.data_ptr(), r2s.data_ptr(), N, m, nc, W.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                            mean.data_ptr(), invstd.data_ptr(), gsite.data_ptr(), dW.data_ptr(), db.data_ptr(), part.data_ptr(), SLOTS,
-                            _l.stream()), 'tail_bwd')
-    mask = ((x * scale + shift) > 0).double()
-    g_rows = (dl.double() @ W.double()) * mask[r2s.long()]
-    g_ref = torch.zeros(n0, m, dtype=torch.float64, device=dev).index_add_(0, r2s.long(), g_rows)
-    assert rel(gsite.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
-    y32 = torch.relu(x * scale + shift).double()
-    assert rel(dW.cpu().numpy(), (dl.double().T @ y32[r2s.long()]).cpu().numpy()) < 1e-5
-    assert rel(db.cpu().numpy(), dl.double().sum(0).cpu().numpy()) < 1e-5
+    dl_all = torch.randn(N, nc, generator=g).to(dev)
     xh = (xd - mean.double()) * invstd.double()
-    s = part.sum(0)
-    assert rel(s[0].cpu().numpy(), g_ref.sum(0).cpu().numpy()) < 1e-6 and rel(s[1].cpu().numpy(), (g_ref * xh).sum(0).cpu().numpy()) < 1e-6
+    mask = ((x * scale + shift) > 0).double()
+    y32 = torch.relu(x * scale + shift).double()
+    # rows that share sites (gradients added onto zeros), then one row per site (n_sites == n: stored, gsite not zeroed)
+    for rows in (N, n0):
+        dl = dl_all[:rows].contiguous(); rs = r2s[:rows].contiguous()
+        gsite = torch.zeros(n0, m, device=dev) if rows != n0 else torch.full((n0, m), float('nan'), device=dev)
+        dW = torch.zeros(nc, m, device=dev); db = torch.zeros(nc, device=dev)
+        part = torch.zeros(SLOTS, 2, m, dtype=torch.float64, device=dev)
+        _l.check(L.urn_tail_bwd(dl.data_ptr(), x.data_ptr(), rs.data_ptr(), rows, m, nc, W.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                mean.data_ptr(), invstd.data_ptr(), gsite.data_ptr(), n0, dW.data_ptr(), db.data_ptr(), part.data_ptr(),
+                                SLOTS, _l.stream()), 'tail_bwd')
+        g_rows = (dl.double() @ W.double()) * mask[rs.long()]
+        g_ref = torch.zeros(n0, m, dtype=torch.float64, device=dev).index_add_(0, rs.long(), g_rows)
+        assert rel(gsite.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
+        assert rel(dW.cpu().numpy(), (dl.double().T @ y32[rs.long()]).cpu().numpy()) < 1e-5
+        assert rel(db.cpu().numpy(), dl.double().sum(0).cpu().numpy()) < 1e-5
+        s = part.sum(0)
+        assert rel(s[0].cpu().numpy(), g_ref.sum(0).cpu().numpy()) < 1e-6 and rel(s[1].cpu().numpy(), (g_ref * xh).sum(0).cpu().numpy()) < 1e-6
     # the model with and without the head inside the executor
     S, mm, Lv = 64, 16, 3
     blob = make_sparse_blob([11, 12], S, 2500)

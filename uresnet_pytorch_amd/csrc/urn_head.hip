@@ -209,82 +209,119 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const float *__restrict__ x, c
 }
 
 // Backward of the same: per input row  y = relu(x * scale + shift) (recomputed),  g = (dl @ W) masked by y > 0, added onto
-// the row's site (several rows may share one: atomics; gsite zeroed by the caller);  dW += dl^T y, db += sum dl (block sums,
-// then atomics);  the BatchNorm-backward column sums  sum g, sum g * xhat  over the ROWS (= over the sites, by linearity)
-// into the accumulated slab `part` ([slots][2][m] doubles) that urn_bn_bwd_apply_sums then reads.
-#define TAIL_ROWS 128
-__global__ __launch_bounds__(TAIL_ROWS) void k_tail_bwd(const float *__restrict__ dl, const float *__restrict__ x,
-                                                        const int *__restrict__ row2site, long n, int m, int nc,
-                                                        const float *__restrict__ W, const float *__restrict__ scale,
-                                                        const float *__restrict__ shift, const float *__restrict__ mean,
-                                                        const float *__restrict__ invstd, float *__restrict__ gsite,
-                                                        float *__restrict__ dW, float *__restrict__ db, double *__restrict__ part,
-                                                        int slots)
+// the row's site;  dW += dl^T y, db += sum dl;  the BatchNorm-backward column sums  sum g, sum g * xhat  over the ROWS (= over
+// the sites, by linearity) into the accumulated slab `part` ([slots][2][m] doubles) that urn_bn_bwd_apply_sums then reads.
+// A thread owns FOUR channels of a row (m / 4 threads per row, 16-byte accesses) and keeps its share of dW, db and of the column
+// sums in registers over all the rows its workgroup walks; the rows of a wave are combined with shuffles, the waves through
+// LDS, the workgroup adds 2 m doubles and nc (m + 1) floats with atomics.  (The first version -- a thread per row, serial
+// sums over LDS columns, one float atomic per (row, channel) onto the site -- took 35 us for 50k rows x 16 channels.)
+// one2one: every site has exactly one row (n == number of sites): g is STORED, and gsite need not be zeroed.
+#define TAILB_THREADS 256
+__global__ __launch_bounds__(TAILB_THREADS) void k_tail_bwd(const float *__restrict__ dl, const float *__restrict__ x,
+                                                            const int *__restrict__ row2site, long n, int m, int nc,
+                                                            const float *__restrict__ W, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, float *__restrict__ gsite,
+                                                            float *__restrict__ dW, float *__restrict__ db, double *__restrict__ part,
+                                                            int slots, int one2one)
 {
-    __shared__ float s_w[HEAD_MAXC * HEAD_MAXM / 8];
-    __shared__ float s_dl[TAIL_ROWS][9];
-    __shared__ float s_y[TAIL_ROWS][TAIL_MAXM / 2 + 1];    // y, then g          (m <= 32 here; wider heads take the unfused route)
-    __shared__ float s_gx[TAIL_ROWS][TAIL_MAXM / 2 + 1];   // g * xhat
-    for (int e = threadIdx.x; e < nc * m; e += TAIL_ROWS) s_w[e] = W[e];
-    const long i = (long)blockIdx.x * TAIL_ROWS + threadIdx.x;
-    const bool ok = i < n;
-    float d[8];
+    __shared__ float s_dw[TAILB_THREADS / 64][8 * 32];
+    __shared__ float s_db[TAILB_THREADS / 64][8];
+    __shared__ double s_pt[TAILB_THREADS / 64][2 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tpr = m >> 2;                       // threads per row: 4 (m = 16) or 8 (m = 32); a power of two (host)
+    const int k = 4 * (tid & (tpr - 1));          // first channel of this thread
+    const int rpp = TAILB_THREADS / tpr;          // rows per pass of the workgroup
+    const f32x4 sc = *(const f32x4 *)(scale + k), sh = *(const f32x4 *)(shift + k);
+    const f32x4 mu = *(const f32x4 *)(mean + k), is = *(const f32x4 *)(invstd + k);
+    f32x4 w[8], dwa[8];
+    float dba[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) d[c] = (ok && c < nc) ? dl[i * nc + c] : 0.f;
+    for (int c = 0; c < 8; ++c) {
+        w[c] = c < nc ? *(const f32x4 *)(W + c * m + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        dwa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dba[c] = 0.f;
+    }
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long row = (long)blockIdx.x * rpp + tid / tpr; row < n; row += (long)gridDim.x * rpp) {
+        float d[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) s_dl[threadIdx.x][c] = d[c];
-    __syncthreads();
-    const long site = ok ? (long)row2site[i] : 0;
-    for (int k = 0; k < m; k += 4) {
-        f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (ok) xv = *(const f32x4 *)(x + site * m + k);
+        for (int c = 0; c < 8; ++c) d[c] = c < nc ? dl[row * nc + c] : 0.f;
+        const long site = (long)row2site[row];
+        const f32x4 xv = *(const f32x4 *)(x + site * m + k);
+        f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int kk = k + j;
-            const float y = ok ? fmaxf(fmaf(xv[j], scale[kk], shift[kk]), 0.f) : 0.f;
-            float g = 0.f;
+            const float y = fmaxf(fmaf(xv[j], sc[j], sh[j]), 0.f);
+            float gj = 0.f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < nc) g = fmaf(d[c], s_w[c * m + kk], g);
-            if (!(y > 0.f)) g = 0.f;
-            const float xh = (xv[j] - mean[kk]) * invstd[kk];
-            s_y[threadIdx.x][kk] = y;
-            s_gx[threadIdx.x][kk] = g * xh;
-            if (ok && g != 0.f) atomicAdd(&gsite[site * m + kk], g);
-            // (g itself is kept in a register image below: s_y is still needed for dW)
+            for (int c = 0; c < 8; ++c) gj = fmaf(d[c], w[c][j], gj);
+            if (!(y > 0.f)) gj = 0.f;
+            const float xh = (xv[j] - mu[j]) * is[j];
+            s0[j] += (double)gj;
+            s1[j] += (double)(gj * xh);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dwa[c][j] = fmaf(d[c], y, dwa[c][j]);
+            g[j] = gj;
+        }
+        if (one2one) {
+            *(f32x4 *)(gsite + site * m + k) = g;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (g[j] != 0.f) atomicAdd(&gsite[site * m + k + j], g[j]);
+        }
+        if (k == 0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dba[c] += d[c];
+        }
+    }
+    // rows of the wave: lanes with the same channels are tpr apart
+    for (int off = tpr; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c >= nc) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dwa[c][j] += __shfl_xor(dwa[c][j], off);
+            dba[c] += __shfl_xor(dba[c], off);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s0[j] += __shfl_xor(s0[j], off); s1[j] += __shfl_xor(s1[j], off); }
+    }
+    if (lane < tpr) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < nc) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s_dw[wave][c * m + k + j] = dwa[c][j];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s_pt[wave][k + j] = s0[j]; s_pt[wave][m + k + j] = s1[j]; }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s_db[wave][c] = dba[c];
         }
     }
     __syncthreads();
-    // dW / db: thread e = (c, k) sums over the block's rows
-    for (int e = threadIdx.x; e < nc * m; e += TAIL_ROWS) {
-        const int c = e / m, k = e - c * m;
+    constexpr int NW = TAILB_THREADS / 64;
+    for (int e = tid; e < nc * m; e += TAILB_THREADS) {
         float acc = 0.f;
-        for (int r = 0; r < TAIL_ROWS; ++r) acc = fmaf(s_dl[r][c], s_y[r][k], acc);
+#pragma unroll
+        for (int v = 0; v < NW; ++v) acc += s_dw[v][e];
         atomicAdd(&dW[e], acc);
     }
-    if (threadIdx.x < nc) {
+    if (tid < nc) {
         float acc = 0.f;
-        for (int r = 0; r < TAIL_ROWS; ++r) acc += s_dl[r][threadIdx.x];
-        atomicAdd(&db[threadIdx.x], acc);
-    }
-    __syncthreads();
-    // g again into s_y (recomputed from dl, W and the mask y > 0 that s_y holds)
-    for (int k = 0; k < m; ++k) {
-        float g = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < nc) g = fmaf(d[c], s_w[c * m + k], g);
-        const bool on = s_y[threadIdx.x][k] > 0.f;
-        s_y[threadIdx.x][k] = on ? g : 0.f;
+        for (int v = 0; v < NW; ++v) acc += s_db[v][tid];
+        atomicAdd(&db[tid], acc);
     }
-    __syncthreads();
-    if (threadIdx.x < 2 * m) {
-        const int k = threadIdx.x < m ? threadIdx.x : threadIdx.x - m;
+    if (tid < 2 * m) {
         double acc = 0.0;
-        if (threadIdx.x < m) { for (int r = 0; r < TAIL_ROWS; ++r) acc += (double)s_y[r][k]; }
-        else { for (int r = 0; r < TAIL_ROWS; ++r) acc += (double)s_gx[r][k]; }
+#pragma unroll
+        for (int v = 0; v < NW; ++v) acc += s_pt[v][tid];
         const long slot = blockIdx.x % (unsigned)slots;
-        unsafeAtomicAdd(&part[(slot * 2 + (threadIdx.x < m ? 0 : 1)) * m + k], acc);
+        unsafeAtomicAdd(&part[slot * 2 * m + tid], acc);
     }
 }
 
@@ -305,13 +342,16 @@ extern "C" int urn_tail_fwd(const float *x, const int32_t *row2site, int64_t n, 
 
 extern "C" int urn_tail_bwd(const float *dlogits, const float *x, const int32_t *row2site, int64_t n, int m, int nc, const float *W,
                             const float *scale, const float *shift, const float *mean, const float *invstd, float *gsite,
-                            float *dW, float *db, double *part, int slots, void *stream)
+                            int64_t n_sites, float *dW, float *db, double *part, int slots, void *stream)
 {
     if (n <= 0) return URN_OK;
     URN_CHECK_ARG(dlogits && x && row2site && W && scale && shift && mean && invstd && gsite && dW && db && part && slots > 0, "null pointer");
-    URN_CHECK_ARG(m > 0 && m % 4 == 0 && m <= TAIL_MAXM / 2 && nc > 0 && nc <= 8 && nc * m <= HEAD_MAXC * HEAD_MAXM / 8, "unsupported head shape (m <= 32, nc <= 8)");
-    hipLaunchKernelGGL(k_tail_bwd, dim3(urn_cdiv(n, TAIL_ROWS)), dim3(TAIL_ROWS), 0, (hipStream_t)stream, dlogits, x, row2site, (long)n, m, nc,
-                       W, scale, shift, mean, invstd, gsite, dW, db, part, slots);
+    URN_CHECK_ARG((m == 16 || m == 32) && nc > 0 && nc <= 8, "unsupported head shape (m 16 or 32, nc <= 8)");
+    const int rpp = TAILB_THREADS / (m / 4);
+    const long passes = urn_cdiv(n, rpp);
+    const long per_wg = urn_cdiv(passes, 1024);     // at most 1024 workgroups, each walking the same number of passes
+    hipLaunchKernelGGL(k_tail_bwd, dim3((unsigned)urn_cdiv(passes, per_wg)), dim3(TAILB_THREADS), 0, (hipStream_t)stream, dlogits, x, row2site,
+                       (long)n, m, nc, W, scale, shift, mean, invstd, gsite, dW, db, part, slots, n_sites == n ? 1 : 0);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }

@@ -1179,10 +1179,11 @@ static void run_backward(urn_net *net, const float *d_rows)
         double *part = net->sums_alloc(b.c);
         float *dx = net->arena.f32(n0 * b.c);
         if (net->live()) {
-            net->check(hipMemsetAsync(d, 0, (size_t)n0 * net->m * 4, net->st) == hipSuccess ? URN_OK : URN_EHIP);
+            // (one row per site: the kernel stores every element of d, nothing to zero)
+            if (net->geo.n_rows != n0) net->check(hipMemsetAsync(d, 0, (size_t)n0 * net->m * 4, net->st) == hipSuccess ? URN_OK : URN_EHIP);
             float *gw = net->grads + net->n_params;
             net->check(urn_tail_bwd(d_rows, b.x, net->geo.row2site, net->geo.n_rows, b.c, net->nc, net->head_w, b.scale, b.shift, b.mean,
-                                    b.invstd, d, gw, gw + (int64_t)net->nc * b.c, part, urn_net::SUM_SLOTS, net->st));
+                                    b.invstd, d, n0, gw, gw + (int64_t)net->nc * b.c, part, urn_net::SUM_SLOTS, net->st));
             net->check(urn_bn_bwd_apply_sums(b.x, d, nullptr, 0, n0, b.c, net->params + b.w, b.mean, b.invstd, part, urn_net::SUM_SLOTS,
                                              net->grads + b.w, net->grads + b.b, dx, net->st));
         }

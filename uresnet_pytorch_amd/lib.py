@@ -164,7 +164,7 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double,
                              c_void_p, c_void_p]),
     'urn_tail_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                             c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'urn_set_option': (c_int, [ctypes.c_char_p, c_i64]),
     'urn_prof_enable': (c_int, [c_int]),
     'urn_prof_read': (c_int, [c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_i64)]),
