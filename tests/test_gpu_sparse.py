@@ -839,6 +839,21 @@ def test_reduced_precision_operands(dev, prec, tol_op, tol_net):
         for got, want in ((y.detach(), y_ref), (xt.grad, dx_ref), (Wt.grad, dW_ref)):
             e = rel(got.cpu().numpy(), want)
             assert 1e-6 < e < tol_op, e      # > 1e-6: the reduced-precision kernels really ran
+        # the weight gradient on the compacted rule lists (two stages, no atomics) with the same operand rounding
+        # (k_dw_pairs<.., PREC>: the four rules a lane loads are the four contraction slots of one 16-bit MFMA), bitwise reproducible
+        so.set_deterministic_dw(True, 'pairs')
+        try:
+            p0 = geo.pairs['nbr'][0]
+            dws = []
+            for _ in range(2):
+                x2 = torch.from_numpy(x).to(dev).requires_grad_(True); W2 = torch.from_numpy(W).to(dev).requires_grad_(True)
+                so.GConvFunction.apply(x2, W2, None, geo.nbr[0], geo.nbr[0], 1, geo.ld, n, n, p0, p0).backward(torch.from_numpy(dy).to(dev))
+                dws.append(W2.grad.detach().clone())
+            e = rel(dws[0].cpu().numpy(), dW_ref)
+            assert 1e-6 < e < tol_op, e
+            assert torch.equal(dws[0], dws[1])
+        finally:
+            so.set_deterministic_dw(False)
         # whole network (executor, fused BatchNorm) against the oracle
         S, m, Lv, nc = 32, 16, 3, 5
         c, f = cloud(6, S, 800, 2, 11)

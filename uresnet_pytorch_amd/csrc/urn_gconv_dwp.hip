@@ -42,7 +42,9 @@ __device__ __forceinline__ void load_n(float (&d)[N], const float *p)
 
 // U, V: 16-channel groups of the input / output side per wave (lane r owns channels U*r .. U*r+U-1 of its block: the row
 // of MFMA u is channel U*i + u, so that a lane's U values are contiguous in memory); XF: rows are relu(x*scale+shift)
-template <int U, int V, int XF, int GB = (U * V <= 4 ? 4 : (U * V <= 9 ? 2 : 1))>
+// PREC: MFMA operand precision (0 fp32: four v_mfma_f32_16x16x4_f32 per block of 16 rules and (u, v); 1 bf16 / 2 fp16: the
+// four rules a lane loads ARE its four contraction slots of ONE v_mfma_f32_16x16x16_*: values rounded at use, fp32 accumulate)
+template <int U, int V, int XF, int PREC = 0, int GB = (U * V <= 4 ? 4 : (U * V <= 9 ? 2 : 1))>
 __global__ __launch_bounds__(64) void k_dw_pairs(DwpArgs g)
 {
     const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(64) void k_dw_pairs(DwpArgs g)
             for (int j = 0; j < GB; ++j) fetch_rows(tl_n[j], pw_n[j], a_n[j], d_n[j]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < GB; ++j)
+            for (int j = 0; j < GB; ++j) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     if constexpr (XF != 0) {
@@ -170,11 +172,34 @@ __global__ __launch_bounds__(64) void k_dw_pairs(DwpArgs g)
                     }
 #pragma unroll
                     for (int v = 0; v < V; ++v) d_c[j][m][v] = pad[j][m] ? 0.f : d_c[j][m][v];
+                    if constexpr (PREC == 0) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+#pragma unroll
+                            for (int v = 0; v < V; ++v) acc[u][v] = MFMA16(a_c[j][m][u], d_c[j][m][v], acc[u][v]);
+                    }
+                }
+                if constexpr (PREC != 0) {
+                    typedef short s16x4 __attribute__((ext_vector_type(4)));
+                    s16x4 ah[U], dh[V];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        ah[u] = __builtin_bit_cast(s16x4, urn_round16x4<PREC>((f32x4){a_c[j][0][u], a_c[j][1][u], a_c[j][2][u], a_c[j][3][u]}));
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        dh[v] = __builtin_bit_cast(s16x4, urn_round16x4<PREC>((f32x4){d_c[j][0][v], d_c[j][1][v], d_c[j][2][v], d_c[j][3][v]}));
 #pragma unroll
                     for (int u = 0; u < U; ++u)
 #pragma unroll
-                        for (int v = 0; v < V; ++v) acc[u][v] = MFMA16(a_c[j][m][u], d_c[j][m][v], acc[u][v]);
+                        for (int v = 0; v < V; ++v) {
+                            if constexpr (PREC == 1) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], dh[v], acc[u][v], 0, 0, 0);
+                            else {
+                                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                                acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, ah[u]), __builtin_bit_cast(h16x4, dh[v]), acc[u][v], 0, 0, 0);
+                            }
+                        }
                 }
+            }
         };
         for (int grp = 0; grp < ngroups; grp += 2) {
             step(grp, pw_e, tl_e, a_e, d_e, pw_o, tl_o, a_o, d_o);
@@ -251,11 +276,17 @@ extern "C" int64_t urn_gconv_dw_pairs_scratch_bytes(int64_t n_out, int tile, int
     return (int64_t)g_dwp_smax * K * cin * cout * 4 + 256;
 }
 
+extern int g_opt_precision;   // urn_set_option("gconv_precision"): operand precision of the gather convolutions and their weight gradients
 template <int U, int V>
 static void launch_dwp(const DwpArgs &a, dim3 grid, hipStream_t st)
 {
-    if (a.xf_scale) hipLaunchKernelGGL((k_dw_pairs<U, V, 1>), grid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_dw_pairs<U, V, 0>), grid, dim3(64), 0, st, a);
+    const int prec = g_opt_precision;
+#define URN_DWP_L(XFv) do { \
+        if (prec == 1) hipLaunchKernelGGL((k_dw_pairs<U, V, XFv, 1>), grid, dim3(64), 0, st, a); \
+        else if (prec == 2) hipLaunchKernelGGL((k_dw_pairs<U, V, XFv, 2>), grid, dim3(64), 0, st, a); \
+        else hipLaunchKernelGGL((k_dw_pairs<U, V, XFv, 0>), grid, dim3(64), 0, st, a); } while (0)
+    if (a.xf_scale) URN_DWP_L(1); else URN_DWP_L(0);
+#undef URN_DWP_L
 }
 
 extern "C" int urn_gconv_bwd_dw_pairs(const float *x, int64_t ldx, const float *xf_scale, const float *xf_shift, const float *dy,

@@ -675,10 +675,19 @@ bool urn_pairs16_p2(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_
 bool urn_pairs16_p3(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);   // fp16, NC 1 | 2
 bool urn_pairs16_p4(int kc, int nc, const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);   // fp16, NC 4
 #if URN_PAIRS_PART != 0
+template <typename F>
+static void pairs_big_lds(F f, size_t lds)
+{
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+}
 template <int KC, int NC, int PREC>
 static void launch_pairs16(const GArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
 {
     const bool xf = a.xf_scale != nullptr || a.xs_sums[0] != nullptr;
+    if (lds > 65536) {
+        pairs_big_lds(k_gconv_pairs<KC, NC, 1, 0, PREC>, lds); pairs_big_lds(k_gconv_pairs<KC, NC, 0, 0, PREC>, lds);
+        if constexpr (NC <= 2) { pairs_big_lds(k_gconv_pairs<KC, NC, 1, 2, PREC>, lds); pairs_big_lds(k_gconv_pairs<KC, NC, 0, 2, PREC>, lds); }
+    }
     if constexpr (NC <= 2) {
         if (a.p_deep == 2) {
             if (xf) hipLaunchKernelGGL((k_gconv_pairs<KC, NC, 1, 2, PREC>), grid, block, lds, st, a);
@@ -726,6 +735,7 @@ int g_pairs_split = 0;
 int g_pairs_split_kc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // force G for inputs of 16 KC channels (urn_set_option "pairs_split_kc<KC>"), 0 = automatic
 int g_pairs_wgs = 512;       // a workgroup takes several column groups only while the launch keeps this many workgroups ("pairs_wgs")
 int g_pairs_v3 = 0x17E;       // bit KC set: the STRIP variant (pair words of a wave's share in LDS, weight block of the next offset requested with the next rows) for one-chunk inputs of 16 KC channels (urn_set_option "pairs_v3")
+int g_pairs_lds_cap16 = 0;   // 16-bit operands: LDS bytes a workgroup may take (urn_set_option "pairs_lds_cap16", 0 = 64 KB; a workgroup may declare up to 160 KB): more column groups / list shares per workgroup at the wide layers.  Measured at the cfg5 shape in fp16: 11.69 -> 11.48 ms per step at 96 KB, the same at 160 KB; 128-row tiles with it 13.3 ms.  Opt-in: the other launch shapes move the small fp16 network's gradient noise (ReLU flips) to the edge of its test bound
 int g_pairs_cbg = 0;          // most column groups per workgroup (urn_set_option "pairs_cbg"), 0 = as many as fit       // force G (urn_set_option "pairs_split"), 0 = automatic
 
 template <int KC, int NC>
@@ -786,19 +796,20 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
         size_t w = (size_t)2 * a.cin + (((size_t)G * (T + 1) * (cw + 4) + 1) & ~(size_t)1);
         return w * 4 + (size_t)2 * G * cw * 8 + (strip ? (size_t)strip_blocks(G) * 17 * 4 + 16 : 0);
     };
+    const int lds_cap = (a.prec != 0 && g_pairs_lds_cap16 > 0) ? g_pairs_lds_cap16 : 65536;   // a workgroup may declare up to 160 KB (one resident workgroup per CU then)
     int G = 1;
     const int want_waves = (a.epi != 2 && g_pairs_waves_fwd > 0) ? g_pairs_waves_fwd : g_pairs_waves;
     for (;;) {
         G = 1;
-        while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < want_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= 65536) ++G;
-        if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= 65536) G = g_pairs_split;
-        if (kc <= 8 && g_pairs_split_kc[kc] > 0 && cbg * g_pairs_split_kc[kc] <= maxw && lds_bytes(g_pairs_split_kc[kc]) <= 65536) G = g_pairs_split_kc[kc];
-        if (lds_bytes(G) <= 65536 || cbg == 1) break;
+        while (G < 8 && cbg * (G + 1) <= maxw && ntiles * cbg_all * G < want_waves && (G + 1) * 2 <= (a.K * (T / 16) + 1) && lds_bytes(G + 1) <= (size_t)lds_cap) ++G;
+        if (g_pairs_split > 0 && cbg * g_pairs_split <= maxw && lds_bytes(g_pairs_split) <= (size_t)lds_cap) G = g_pairs_split;
+        if (kc <= 8 && g_pairs_split_kc[kc] > 0 && cbg * g_pairs_split_kc[kc] <= maxw && lds_bytes(g_pairs_split_kc[kc]) <= (size_t)lds_cap) G = g_pairs_split_kc[kc];
+        if (lds_bytes(G) <= (size_t)lds_cap || cbg == 1) break;
         // slabs + strips of this many column groups do not fit 64 KB of LDS: fewer column groups per workgroup
         do { --cbg; } while (cbg > 1 && cbg_all % cbg);
         gy = cbg_all / cbg; cw = 16 * nc * cbg;
     }
-    if (lds_bytes(G) > 65536) return 0;
+    if (lds_bytes(G) > (size_t)lds_cap) return 0;
     a.p_split = G; a.p_cw = cw; a.p_deep = strip ? 2 : 0; a.p_strip = strip ? strip_blocks(G) : 0;
     const dim3 grid((unsigned)ntiles, gy), block(64 * cbg * G);
     const size_t lds = lds_bytes(G);
