@@ -243,7 +243,9 @@ typedef struct {
      * cycle, and the weight block is fetched again for nearly every block of 16 rules.  NULL: rows of wt. */
     const float *wt_frag;
     /* Element type of wt_frag: 0 = fp32 (above), 1 = bf16, 2 = fp16 (urn_weight_fragments16: the same order with 16-bit
-     * elements, 512 bytes per 16 x 16 block -- a lane's 8 bytes ARE its A operand of v_mfma_f32_16x16x16_*).  The
+     * elements, 512 bytes per 16 x 16 block -- a lane's 8 bytes ARE its A operand of v_mfma_f32_16x16x16_*; when cin / 16
+     * is even, blocks kb and kb + 1 (kb even) share one kilobyte with a lane's 16 bytes = [its 8 of kb | its 8 of kb + 1]:
+     * one 16-byte load per lane, the A operand of v_mfma_f32_16x16x32_*).  The
      * reduced-precision variants of the pair-list kernel run only on fragments of their own precision (they keep the
      * weight blocks of an offset in half the registers and take two to four column blocks per wave); any other
      * combination runs on the 2-D tile kernel. */

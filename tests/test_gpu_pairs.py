@@ -299,10 +299,14 @@ def test_pairs_reduced_precision_on_16bit_fragments(dev, cin, cout, prec, tol):
     wt = (torch.randn(27, cout, cin, generator=g) * 0.1).to(dev)
     wf16 = torch.empty(27 * cout * cin, dtype=torch.int16, device=dev)
     _l.check(L.urn_weight_fragments16(wt.data_ptr(), 27, cout, cin, prec, wf16.data_ptr(), _l.stream()), 'weight_fragments16')
-    # the layout the header states, with 16-bit elements
-    o, cb, kb, q, r, i = 5, cout // 16 - 1, cin // 16 - 1, 2, 7, 3
-    got = wf16.view(torch.bfloat16 if prec == 1 else torch.float16)[((o * (cout // 16) + cb) * (cin // 16) + kb) * 256 + (q * 16 + r) * 4 + i]
-    assert float(got) == float(wt[o, 16 * cb + r, 16 * kb + 4 * q + i].to(got.dtype))
+    # the layout the header states, with 16-bit elements: 8 bytes per lane and block; an even number of 16-channel groups
+    # pairs the blocks (kb, kb + 1) in one kilobyte, a lane's 16 bytes = [its 8 of kb | its 8 of kb + 1]
+    kbn = cin // 16
+    for o, cb, kb, q, r, i in ((5, cout // 16 - 1, kbn - 1, 2, 7, 3), (26, 0, 0, 3, 15, 0), (11, cout // 32, kbn // 2, 1, 0, 2)):
+        blk, lane = (o * (cout // 16) + cb) * kbn + kb, q * 16 + r
+        slot = blk * 64 + lane if kbn % 2 else ((blk & ~1) << 6) + 2 * lane + (blk & 1)
+        got = wf16.view(torch.bfloat16 if prec == 1 else torch.float16)[slot * 4 + i]
+        assert float(got) == float(wt[o, 16 * cb + r, 16 * kb + 4 * q + i].to(got.dtype))
     wf32 = torch.empty_like(wt)
     _l.check(L.urn_weight_fragments(wt.data_ptr(), 27, cout, cin, wf32.data_ptr(), _l.stream()), 'weight_fragments')
     pl = geo.pairs['nbr'][0]

@@ -3,7 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
 import numpy as np, torch
-from uresnet_pytorch_amd import parallel
+from uresnet_pytorch_amd import parallel, lib as L_
+if os.environ.get('URN_LIB_PATH'): L_.LIB_PATH = os.environ['URN_LIB_PATH']   # diagnostic build (tools/build_diag_lib.sh)
 from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
 from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
 dev = torch.device('cuda:0')

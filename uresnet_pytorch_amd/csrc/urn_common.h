@@ -65,6 +65,19 @@ __device__ __forceinline__ void urn_slab_sum2(const double *p, long ld, int slot
     for (; k < slots; ++k) { v0 += p[(long)(2 * k) * ld]; v1 += p[(long)(2 * k + 1) * ld]; }
 }
 
+// 16-bit weight fragments (urn_gconv_args.wt_frag_prec != 0): where the 8 bytes of lane `lane` of block (.., kb) go, in
+// 8-byte units.  e = linear index with the 16-channel group kb fastest, then the lane (the fp32 order scaled down).  With an
+// EVEN number of groups two consecutive groups share a kilobyte, a lane's 16 bytes = [group kb | group kb + 1]: one
+// 16-byte load fetches both -- they are the eight contraction slots of ONE v_mfma_f32_16x16x32_* (the pair-list loop is
+// bound by the vector-memory INSTRUCTIONS a CU can issue, and the weight blocks were 32 of its 43 per block at 128 -> 64x4).
+__host__ __device__ __forceinline__ long urn_frag16_slot(long e, int kbn)
+{
+    if (kbn & 1) return e;
+    const long blk = e >> 6;               // (.., kb)
+    const int lane = (int)(e & 63);
+    return ((blk & ~1L) << 6) + 2 * lane + (blk & 1);   // kbn even: blk even <=> kb even
+}
+
 // four floats rounded (RNE) to bf16 (PREC 1) or fp16 (PREC 2), packed into 8 bytes: one lane's operand of v_mfma_f32_16x16x16_*
 template <int PREC>
 __device__ __forceinline__ uint2 urn_round16x4(f32x4 v)

@@ -703,7 +703,7 @@ __global__ void k_weight_fragments16(const float *__restrict__ wt, long total4, 
     const int kbn = cin / 16, cbn = cout / 16;
     const int kb = (int)(f % kbn); f /= kbn;
     const int cb = (int)(f % cbn); const long o = f / cbn;
-    wf[e] = urn_round16x4<PREC>(*(const f32x4 *)(wt + ((long)o * cout + 16 * cb + r) * cin + 16 * kb + 4 * q));
+    wf[urn_frag16_slot(e, kbn)] = urn_round16x4<PREC>(*(const f32x4 *)(wt + ((long)o * cout + 16 * cb + r) * cin + 16 * kb + 4 * q));
 }
 
 extern "C" int urn_weight_fragments16(const float *wt, int K, int cout, int cin, int precision, void *wt_frag16, void *stream)

@@ -143,6 +143,20 @@ __device__ __forceinline__ urn_s16x4 pairs_cvt16(f32x4 v)
 template <int PREC> struct PairsW { typedef f32x4 type; };
 template <> struct PairsW<1> { typedef urn_s16x4 type; };
 template <> struct PairsW<2> { typedef urn_s16x4 type; };
+// two 16-channel groups at once: the lane's eight contraction slots = [group j | group j + 1] on BOTH operands (gfx950)
+template <int PREC>
+__device__ __forceinline__ f32x4 pairs_mfma32(urn_s16x4 a0, urn_s16x4 a1, urn_s16x4 b0, urn_s16x4 b1, f32x4 c)
+{
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    if constexpr (PREC == 1) {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    } else {
+        typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    }
+}
 template <int PREC>
 __device__ __forceinline__ f32x4 pairs_mfma16(urn_s16x4 a, urn_s16x4 b, f32x4 c)
 {
@@ -391,6 +405,19 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
         if constexpr (PREC != 0) {
             // 16-bit fragments (the launcher guarantees g.wfrag_prec == PREC): 8 bytes per lane, 512 per block
             const int so = ((o * (cout / 16) + cb0) * kbn + ch * KC) * 512;
+            if constexpr (KC % 2 == 0) {
+                // paired fragments (urn_frag16_slot: kbn = KC * nch is even): one 16-byte load = groups j and j + 1
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int j = 0; j < KC; j += 2) {
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        const s16x8 v = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, so + (c * kbn + j) * 512, 0));
+                        w[j][c] = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+                        w[j + 1][c] = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+                    }
+                return;
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -472,7 +499,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
             int pv_c2 = strip[r];
             const int i1 = nb > 1 ? 1 : 0;
             int pv_n2 = strip[i1 * 16 + r], pl_n2 = strip[i1 * 16 + gp];
-            int t_n = __builtin_amdgcn_readfirstlane(strip_t[i1]);
+            int t_n = URN_DBG(g, 512) ? t_c : __builtin_amdgcn_readfirstlane(strip_t[i1]);
             ready2(a_nxt, a_cur);
             for (int i = 0; i < nb; ++i) {
                 const int i2 = i + 2 < nb ? i + 2 : nb - 1;
@@ -493,6 +520,11 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
                         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                             for (int c = 0; c < NC; ++c) acc[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc[c]);
+                } else if constexpr (KC % 2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < KC; j += 2)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) acc[c] = pairs_mfma32<PREC>(w_cur[j][c], w_cur[j + 1][c], a_cur[j], a_cur[j + 1], acc[c]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < KC; ++j)
@@ -512,7 +544,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
                     }
                 }
                 pv_c2 = pv_n2; pv_n2 = pv_nn; pl_n2 = pl_nn;
-                t_c = t_n; t_n = __builtin_amdgcn_readfirstlane(tv_nn);
+                t_c = t_n; t_n = URN_DBG(g, 512) ? t_c : __builtin_amdgcn_readfirstlane(tv_nn);
             }
         }
     }
@@ -556,6 +588,14 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
                                 if (tt & 1) acc2[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc2[c]);
                                 else acc[c] = MFMA16(w_cur[j][c][tt], a_cur[j][tt], acc[c]);
                             }
+                } else if constexpr (KC % 2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < KC; j += 2)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            if (j & 2) acc2[c] = pairs_mfma32<PREC>(w_cur[j][c], w_cur[j + 1][c], a_cur[j], a_cur[j + 1], acc2[c]);
+                            else acc[c] = pairs_mfma32<PREC>(w_cur[j][c], w_cur[j + 1][c], a_cur[j], a_cur[j + 1], acc[c]);
+                        }
                 } else {
 #pragma unroll
                     for (int j = 0; j < KC; ++j)
@@ -762,7 +802,7 @@ int urn_gconv_pairs_launch(GArgs a, long n_out, hipStream_t st)
     const int ks = a.cin / 16, nblk = a.cout / 16;
     int kc = 1;
     for (int d : {8, 6, 5, 4, 3, 2})
-        if (ks % d == 0) { kc = d; break; }
+        if (ks % d == 0 && (a.prec == 0 || (ks & 1) || !(d & 1))) { kc = d; break; }   // 16-bit fragments of an even group count are PAIRED (urn_frag16_slot): even chunks
     const long ntiles = (n_out + T - 1) / T;
     if ((double)ntiles * (double)urn_pairs_words(a.K, T) * 4.0 >= 2147483648.0) return 0;   // 32-bit offsets into the lists (rows / weights: the dispatcher's off32_ok)
     // two column blocks per wave halve the gathers (every wave of a tile gathers the same rows) when the launch still has

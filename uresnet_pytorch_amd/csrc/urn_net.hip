@@ -882,7 +882,7 @@ __global__ void k_fragments_all(TDescs t, const float *__restrict__ wt_all, cons
         const f32x4 v = *(const f32x4 *)(src + ((long)o * cout + 16 * cb + r) * cin + 16 * kb + 4 * q);
         // PREC != 0: 16-bit fragments (urn_gconv_args.wt_frag_prec) in the first half of the conv's region
         if constexpr (PREC == 0) *(f32x4 *)(dst + e * 4) = v;
-        else ((uint2 *)dst)[e] = urn_round16x4<PREC>(v);
+        else ((uint2 *)dst)[urn_frag16_slot(e, kbn)] = urn_round16x4<PREC>(v);
     }
 }
 
