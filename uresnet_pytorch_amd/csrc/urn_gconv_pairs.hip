@@ -267,27 +267,29 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     // then restored across the lanes (ds_bpermute_b32: lane (r, q) takes the registers of lane 4 r + q).
     const int gp = lane >> 2, gq = lane & 3;               // gather pair / 16-byte piece of this lane
     const int bp_addr = 4 * (4 * r + q);                   // byte address of the source lane for ds_bpermute
-    auto load_idx = [&](int b, int &pv, int &tv, int &pl) {
+    // per block ONE vector load (the pair word of lane & 15) and one scalar load (the block's table row): the gather row of
+    // lane l -- the word of pair l >> 2 -- is taken from lane l >> 2 with ds_bpermute when the rows are requested (the loop is
+    // bound by the vector-memory instructions a CU can issue; this was three per block)
+    auto load_idx = [&](int b, int &pv, int &tv) {
         if (ident) {
-            const int lr = 16 * b + r, lg = 16 * b + gp;
+            const int lr = 16 * b + r;
             pv = lr < rows_here ? (((int)row0 + lr) | (lr << 24)) : (T << 24);
-            pl = lg < rows_here ? (int)row0 + lg : 0;
             tv = 0;
             return;
         }
         const int so = (pw_p + b * 16) * 4;   // scalar (b is)
         pv = __builtin_amdgcn_raw_buffer_load_b32(rs_p, r * 4, so, 0);
-        pl = __builtin_amdgcn_raw_buffer_load_b32(rs_p, gp * 4, so, 0);
-        tv = URN_DBG(g, 512) ? 0 : (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, 0, (pw_t + b) * 4, 0);   // same word in every lane; made scalar (readfirstlane) only where it is used, two blocks later
+        tv = URN_DBG(g, 512) ? 0 : g.pairs[pw_t + b];   // wave-uniform address: s_load
     };
+    auto gather_word = [&](int pv) { return __builtin_amdgcn_ds_bpermute(4 * gp, pv); };
     // the first pair words of the wave's share are requested BEFORE the statistics of the folded BatchNorm are fetched and
     // finalized below: two round trips side by side instead of one after the other at the head of every folding launch
-    int pv_c = 0, tv_c = 0, pv_n = 0, tv_n = 0, pv_nn = 0, tv_nn = 0, pl_c = 0, pl_n = 0, pl_nn = 0;
+    int pv_c = 0, tv_c = 0, pv_n = 0, tv_n = 0, pv_nn = 0, tv_nn = 0;
     if constexpr (DEEP == 0) {
         if (b0 < b1) {
-            load_idx(b0, pv_c, tv_c, pl_c);
-            load_idx(b0 + 1 < b1 ? b0 + 1 : b1 - 1, pv_n, tv_n, pl_n);
-            load_idx(b0 + 2 < b1 ? b0 + 2 : b1 - 1, pv_nn, tv_nn, pl_nn);
+            load_idx(b0, pv_c, tv_c);
+            load_idx(b0 + 1 < b1 ? b0 + 1 : b1 - 1, pv_n, tv_n);
+            load_idx(b0 + 2 < b1 ? b0 + 2 : b1 - 1, pv_nn, tv_nn);
         }
     }
     if constexpr (XF != 0) {
@@ -555,13 +557,15 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
     // counts in issue order) leaves the younger row loads in flight.
     if (b0 < b1) {
         int t_c = __builtin_amdgcn_readfirstlane(tv_c);
+        int pl_c = gather_word(pv_c);
         load_a(a_nxt, pl_c, 0);
         ready(a_nxt, a_cur, 0);
         int w_key = -1;
         for (int b = b0; b < b1; ++b) {
-            int pv_n3, tv_n3, pl_n3;
-            load_idx(b + 3 < b1 ? b + 3 : b1 - 1, pv_n3, tv_n3, pl_n3);
+            int pv_n3, tv_n3;
+            load_idx(b + 3 < b1 ? b + 3 : b1 - 1, pv_n3, tv_n3);
             const int t_n = __builtin_amdgcn_readfirstlane(tv_n);
+            const int pl_n = gather_word(pv_n);
             // old slab values of this block's rows: requested now, needed after the MFMAs
             float *dptr = slab + (long)((unsigned)pv_c >> 24) * LDW + 4 * q;
             f32x4 old[NC];
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(URN_PAIRS_REGS(KC, NC, PREC) <= 64 ? 1024 : 512, (K
 #pragma unroll
             for (int c = 0; c < NC; ++c) *(f32x4 *)(dptr + 16 * c) = old[c] + (acc[c] + acc2[c]);
             pv_c = pv_n; pv_n = pv_nn; pv_nn = pv_n3;
-            pl_c = pl_n; pl_n = pl_nn; pl_nn = pl_n3;
+            pl_c = pl_n;
             t_c = t_n; tv_n = tv_nn; tv_nn = tv_n3;
         }
     }
