@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
                                                    const float *__restrict__ xf_shift, const float *__restrict__ dy,
                                                    const int *__restrict__ tbl, long ld, long n_out, int cin,
                                                    int cout, long chunk, int n_ci_tiles,
-                                                   float *__restrict__ dw, long ld_dy, float *__restrict__ slab)
+                                                   float *__restrict__ dw, long ld_dy, float *__restrict__ slab, int row_ok)
 {
     __shared__ int s_in[DW2_LIST], s_out[DW2_LIST];
     __shared__ int s_cnt[16];
@@ -255,6 +255,13 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
         // KT > 32 (one or two blocks, S == 1): wave -> block wave % nblk, and the batch's k-steps are split
         const int blk = KT == 32 ? min(wave + 4 * s, nblk - 1) : wave % nblk;
         mi_[s] = blk / ni_n; ni_[s] = blk - mi_[s] * ni_n;
+    }
+    // full-width tiles (four input-channel blocks): wave w owns input block w and ALL output blocks -- its x fragment of a
+    // k-step is read from LDS once for the S MFMAs instead of once per MFMA (6 transposing reads per 5 MFMAs instead of 10)
+    const bool rowmode = row_ok && KT == 32 && mi_n == 4;
+    if (rowmode) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) { mi_[s] = wave; ni_[s] = min(s, ni_n - 1); }
     }
     constexpr int WPB = KT == 128 ? 4 : (KT == 64 ? 2 : 1);   // waves per block
     constexpr int KPM = PREC ? 16 : 4;                          // pairs contracted by one MFMA
@@ -376,31 +383,42 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
                 else if constexpr (i == 9) park_b(b + 1, buf ^ 1, SN(), I2());
             };
             constexpr int PER = (10 + S - 1) / S;
+            typedef short s16x4k __attribute__((ext_vector_type(4)));
+            s16x4k av_keep[2] = {};
             auto group = [&](auto ss) {
                 constexpr int sl = decltype(ss)::value;
+                if constexpr (PREC == 0) {
 #pragma unroll
-                for (int kk = 0; kk < KSW; ++kk) {
-                    const int ks = ks0 + kk;
-                    if constexpr (PREC == 0) {
+                    for (int kk = 0; kk < KSW; ++kk) {
+                        const int ks = ks0 + kk;
                         const float av = s_a[buf][4 * ks + q][mi_[sl] * 16 + m];
                         const float bv = s_b[buf][4 * ks + q][ni_[sl] * 16 + m];
                         acc[sl] = MFMA16(av, bv, acc[sl]);
+                    }
+                } else {
+                    // lane (m, q): pairs 16 ks + 4 q + i (i < 4) of channel m of the block = one transposing read of the
+                    // pair-major tile (ds_read_b64_tr_b16; four ds_read_u16 per operand made the 16-bit kernel
+                    // LDS-instruction bound: 8 reads per MFMA).  The wave's two k-steps of a batch (KSW == 2 for every KT) are the
+                    // eight contraction slots of ONE v_mfma_f32_16x16x32_*: slots 0-3 = pairs 4 q + i of the first step, 4-7 of the second
+                    static_assert(KSW == 2, "16-bit operands: two k-steps of 16 pairs per wave and batch");
+                    typedef short s16x4 __attribute__((ext_vector_type(4)));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                    const int tr_row = 16 * ks0 + 4 * q + (m >> 2), tr_col = 4 * (m & 3);
+                    if (sl == 0 || !rowmode) {
+                        av_keep[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)((unsigned short *)&s_a[buf][tr_row][0] + mi_[sl] * 16 + tr_col));
+                        av_keep[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)((unsigned short *)&s_a[buf][tr_row + 16][0] + mi_[sl] * 16 + tr_col));
+                    }
+                    const s16x4 bv0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)((unsigned short *)&s_b[buf][tr_row][0] + ni_[sl] * 16 + tr_col));
+                    const s16x4 bv1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)((unsigned short *)&s_b[buf][tr_row + 16][0] + ni_[sl] * 16 + tr_col));
+                    const s16x8 a8 = __builtin_shufflevector(av_keep[0], av_keep[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s16x8 b8 = __builtin_shufflevector(bv0, bv1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if constexpr (PREC == 1) {
+                        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                        acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8), acc[sl], 0, 0, 0);
                     } else {
-                        // lane (m, q): pairs 16 ks + 4 q + i (i < 4) of channel m of the block = one transposing read of the
-                        // pair-major tile (ds_read_b64_tr_b16; four ds_read_u16 per operand made the 16-bit kernel
-                        // LDS-instruction bound: 8 reads per MFMA)
-                        typedef short s16x4 __attribute__((ext_vector_type(4)));
-                        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                        const int tr_row = 16 * ks + 4 * q + (m >> 2), tr_col = 4 * (m & 3);
-                        const s16x4 av = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)((unsigned short *)&s_a[buf][tr_row][0] + mi_[sl] * 16 + tr_col));
-                        const s16x4 bv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)((unsigned short *)&s_b[buf][tr_row][0] + ni_[sl] * 16 + tr_col));
-                        if constexpr (PREC == 1) {
-                            acc[sl] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc[sl], 0, 0, 0);
-                        } else {
-                            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-                            acc[sl] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, av), __builtin_bit_cast(h16x4, bv),
-                                                                            acc[sl], 0, 0, 0);
-                        }
+                        typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+                        acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a8), __builtin_bit_cast(h16x8, b8), acc[sl], 0, 0, 0);
                     }
                 }
                 if constexpr (sl * PER + 0 < 10) piece(std::integral_constant<int, sl * PER + 0>());
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw2(const float *__restrict__ x, 
     float *dst = slab ? slab + ((long)chunk_id * WPB + (KT > 32 ? wave / nblk : 0)) * wn : dw;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        if (KT > 32 || wave + 4 * s < nblk) {   // split batches: every wave holds a partial of its block
+        if (KT > 32 || (rowmode ? s < ni_n : wave + 4 * s < nblk)) {   // split batches: every wave holds a partial of its block
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ci = ci0 + mi_[s] * 16 + q * 4 + i, co = co0 + ni_[s] * 16 + m;
@@ -507,6 +525,7 @@ __global__ __launch_bounds__(256) void k_gconv_dw_small(const float *__restrict_
 
 extern int g_opt_precision;
 int g_dw_split = 2;       // split-batch variants of k_gconv_dw2 for one- and two-block tiles: 0 never, 1 automatic, 2 always (urn_set_option "dw_split")
+int g_dw_rowmode = 1;     // full-width tiles: wave w owns input-channel block w and all output blocks (urn_set_option "dw_rowmode": 0 never, 1 with 16-bit operands, 2 always)
 int g_dw_kernel = 2;      // 2 = k_gconv_dw2 (default), 1 = k_gconv_dw (urn_set_option "dw_kernel")
 int g_dw_blocks = 768;    // target number of workgroups of the weight-gradient kernel (urn_set_option "dw_blocks"); alone 2048 is the optimum; beside the dX chain fewer are better (round 1: 3.44 ms per cfg3 step at 1024-1280 against 3.50 at 1536 and 3.57 at 2048; round 2, pair-list dX kernels: 3.20 at 768 = three per CU, 3.22 at 640, 3.23 at 896, 3.24 at 1024-1152, 3.33 at 512, 4.07 at 256 where the side stream becomes the critical path)
 
@@ -618,6 +637,7 @@ static int dw_launch(const float *x, const float *xf_scale, const float *xf_shif
     if (prof) urn_prof_begin(URN_PROF_DW, st);
     const dim3 grid(chunks, K, n_ci_tiles * n_co_tiles);
     const int prec = g_opt_precision;   // 0 fp32, 1 bf16, 2 fp16 (urn_set_option "gconv_precision")
+    const int row_ok = g_dw_rowmode == 2 || (g_dw_rowmode == 1 && prec != 0);
     if (g_dw_kernel == 2) {
         const int ci_w = cin < DW_MAXI * 16 ? cin : DW_MAXI * 16, co_w = cout < DW_MAXN * 16 ? cout : DW_MAXN * 16;
         const int nblk_max = (ci_w / 16) * (co_w / 16);   // of the widest tile
@@ -627,11 +647,11 @@ static int dw_launch(const float *x, const float *xf_scale, const float *xf_shif
 #define URN_DW2P(Sv, XFv, KTv)                                                                                                       \
         do {                                                                                                                         \
             if (prec == 1) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 1>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, \
-                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab);        \
+                                              (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab, row_ok);        \
             else if (prec == 2) hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 2>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, \
-                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab); \
+                                                   tbl, (long)ld, (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab, row_ok); \
             else hipLaunchKernelGGL((k_gconv_dw2<Sv, XFv, KTv, 0>), grid, dim3(256), 0, st, x, xf_scale, xf_shift, dy, tbl, (long)ld, \
-                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab);                            \
+                                    (long)n_out, cin, cout, chunk, n_ci_tiles, dw, (long)ld_dy, slab, row_ok);                            \
         } while (0)
 #define URN_DW2K(Sv, KTv)                                                                                                            \
         if (xf_scale) URN_DW2P(Sv, 1, KTv);                                                                                          \

@@ -321,7 +321,7 @@ static const int g_opt_fin_in_kernel = 0;   // (the in-kernel finalize lived in 
 static int g_opt_pipe = 0;
 static int g_opt_kernel = 7;   // 7 = compacted rule lists when the call carries them (urn_gconv_pairs.hip), else the 2-D tile; 6 = 2-D workgroup tile (urn_gconv_tile.hip); 3 = register gather (fallback for shapes without a tile instantiation)
 extern int g_pairs_split_kc[9];
-extern int g_pairs_lds_cap16;
+extern int g_pairs_lds_cap16, g_dw_rowmode;
 extern int g_pairs_waves, g_pairs_waves_fwd, g_pairs_nc, g_pairs_split, g_pairs_cbg, g_pairs_wgs, g_pairs_wgs16, g_dwp_waves, g_dwp_smax, g_dwp_dbg, g_dwp_cap;
 // which calls that carry a pair list run on the pair-list kernel (measured per shape on the cfg3 geometry, tools/bench_pairs.py:
 // it wins for the strided pair and the narrow levels; the wide, small levels are faster on the LDS-staged 2-D tile kernel):
@@ -348,6 +348,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "pairs_nin")) { g_pairs_nin = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_nc")) { g_pairs_nc = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_cbg")) { g_pairs_cbg = (int)value; return URN_OK; }
+    if (!strcmp(key, "dw_rowmode")) { g_dw_rowmode = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_lds_cap16")) { g_pairs_lds_cap16 = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_wgs")) { g_pairs_wgs = (int)value; return URN_OK; }
     if (!strcmp(key, "pairs_waves_fwd")) { g_pairs_waves_fwd = (int)value; return URN_OK; }
