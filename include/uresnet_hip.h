@@ -369,6 +369,14 @@ int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *dy, int64_t 
                  void *stream);
 int urn_dense_fold(const float *dxp, float *dx, int batch, const int *dims, const int *pad_lo, const int *pad_hi, int c,
                    void *stream);
+/* Input gradient of a stride-1 convolution on the replicate-padded input, un-padding included: urn_dense_conv with gm =
+ * the geometry of the PADDED volume (dy rows -> dxp rows, weights [tap][cin][cout]) followed by urn_dense_fold into dx
+ * (rows of the volume itself, dims = Z, Y, X) -- as one call, so that the 3 x 3 x 3 fast path can write the voxels inside
+ * the volume straight to dx (only the border shell goes to dxp, and only the boundary voxels are folded).  dxp: the padded
+ * volume's rows (scratch, contents undefined afterwards); ld_dx == cin. */
+int urn_dense_conv_dgrad_fold(const float *dy, int64_t ld_dy, int cout, const float *wb, float *dxp, float *dx, int64_t ld_dx,
+                              int cin, int batch, const urn_dense_geom *gm, const int *dims, const int *pad_lo, const int *pad_hi,
+                              int precision, void *scratch, int64_t scratch_bytes, void *stream);
 /* Both weight layouts urn_dense_conv reads -- forward [tap][cout_p][cin_p], input gradient [tap][cin_p][cout_p], channel
  * counts zero-padded -- of n convolutions in ONE launch, from torch's parameter layouts: descs = n records of 11 int64:
  * src, fwd, bwd (device pointers), taps, transposed (0: nn.Conv (cout, cin, taps); 1: nn.ConvTranspose (cin, cout, taps)),

@@ -50,6 +50,11 @@ struct DenseArgs {
     long long *stamps;                              // diagnostics (-DURN_DENSE_STAMP, urn_set_option "dense_stamp_ptr")
     double *stats;                                  // optional [stat_slots][2][cout]: column sums / sums of squares of y ADDED (fp64 atomics)
     int stat_slots;
+    // input gradient on the padded volume with the un-padding folded in (k_dense_conv3 only): outputs whose padded position
+    // minus fold_lo lies inside fold_in go straight to fold_y (rows of the un-padded volume, row stride ldy), only the
+    // border shell is written to y -- k_dense_fold_border then adds the shell onto the boundary voxels
+    float *fold_y;
+    int fold_lo[3], fold_in[3];
 };
 
 // Column statistics of the outputs a workgroup has just computed (the BatchNorm that follows every convolution of the dense
@@ -498,6 +503,10 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
         const long rowz = (long)b * g.Out[0] * g.Out[1] * g.Out[2] + ((long)(g.p[0] + uz) * g.Out[1] + (g.p[1] + uy)) * g.Out[2] + g.p[2];
         const long nsub = (long)g.B * g.Sub[0] * g.Sub[1] * g.Sub[2];
         const long srow0 = (((long)b * g.Sub[0] + uz) * g.Sub[1] + uy) * g.Sub[2];
+        // folded un-padding: is this row block inside the un-padded volume in z and y, and where does its row start there
+        const int fz = g.p[0] + uz - g.fold_lo[0], fy = g.p[1] + uy - g.fold_lo[1];
+        const bool fold_zy = g.fold_y && (unsigned)fz < (unsigned)g.fold_in[0] && (unsigned)fy < (unsigned)g.fold_in[1];
+        const long frow = (((long)b * g.fold_in[0] + fz) * g.fold_in[1] + fy) * g.fold_in[2] + (g.p[2] - g.fold_lo[2]);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
             const int col = col_w0 + 16 * c + r;
@@ -509,7 +518,8 @@ __global__ __launch_bounds__(512, (KC * NCB <= 4 && KC < 4) ? 4 : 2) void k_dens
                 if (split) g.slab[((long)blockIdx.z * nsub + srow0 + ux) * g.cout + col] = acc[i][c][k];
                 else {
                     const float v = acc[i][c][k] + bv;
-                    g.y[(rowz + ux) * g.ldy + col] = v;
+                    if (fold_zy && (unsigned)(g.p[2] + ux - g.fold_lo[2]) < (unsigned)g.fold_in[2]) g.fold_y[(frow + ux) * g.ldy + col] = v;
+                    else g.y[(rowz + ux) * g.ldy + col] = v;
                     if (stats) { d0[c] += (double)v; d1[c] += (double)v * (double)v; }
                 }
             }
@@ -610,6 +620,10 @@ extern "C" int64_t urn_dense_conv_scratch_bytes(int cout, int batch, const urn_d
     if (nsub * cout / (64 * 16) >= 4096) return 256;
     return 32 * nsub * cout * 4 + 256;
 }
+
+// armed by urn_dense_conv_dgrad_fold around its urn_dense_conv call: the un-padding target of an input gradient; `used` is set
+// when the launch took it (3 x 3 x 3 fast path without a split contraction)
+static thread_local struct { bool armed, used; float *y; int lo[3], in[3]; } g_fold = {false, false, nullptr, {0, 0, 0}, {0, 0, 0}};
 
 extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float *wt, const float *bias, float *y, int64_t ldy,
                               int cout, int batch, const urn_dense_geom *gm, int precision, double *stats, int stat_slots,
@@ -740,6 +754,11 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
                     if (scratch_bytes < (int64_t)a.zc * a.zt * nsub * cout * 4) a.zc = a.zt = 1;
                 }
                 a.slab = a.zc * a.zt > 1 ? (float *)scratch : nullptr;
+                if (g_fold.armed && !a.slab && rev == 1) {
+                    a.fold_y = g_fold.y;
+                    for (int d = 0; d < 3; ++d) { a.fold_lo[d] = g_fold.lo[d]; a.fold_in[d] = g_fold.in[d]; }
+                    g_fold.used = true;
+                }
                 const dim3 grid3((unsigned)tiles, gy3, a.zc * a.zt);
                 // (one flag per instantiation: the attribute call is a host round trip into the runtime, ~100 of them per dense step otherwise)
 #define URN_D3(P, K, N, R) if (precision == P && kc3 == K && ncb == N && rev == R) { \
@@ -791,6 +810,53 @@ __global__ void k_dense_fold(const float *__restrict__ dxp, float *__restrict__ 
     *(f32x4 *)(dx + ((((long)b * Z + z) * Y + y) * X + x) * c + 4 * k4) = s;
 }
 
+// the same for a dx whose voxels already hold their OWN padded position (written by the input-gradient launch itself,
+// DenseArgs.fold_y): only the boundary voxels do anything -- they add the shell positions that clamp to them
+__global__ void k_dense_fold_border(const float *__restrict__ dxp, float *__restrict__ dx, int B, int Z, int Y, int X, int lz, int hz,
+                                    int ly, int hy, int lx, int hx, int c)
+{
+    // threads = the voxels of the boundary only (128^3: 97k of 2.1M; a thread per voxel of the volume that leaves at once was
+    // bound by the launch rate of its 32,768 workgroups: 36 us), in three disjoint groups: the two z faces | the y faces of
+    // the inner z planes | the x faces of the inner (z, y) rows
+    const int c4 = c / 4;
+    const int nzf = Z < 2 ? Z : 2, nyf = Y < 2 ? Y : 2, nxf = X < 2 ? X : 2, Zi = Z > 2 ? Z - 2 : 0, Yi = Y > 2 ? Y - 2 : 0;
+    const long n1 = (long)nzf * Y * X, n2 = (long)Zi * nyf * X, n3 = (long)Zi * Yi * nxf, nb = n1 + n2 + n3;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)B * nb * c4) return;
+    const int k4 = (int)(e % c4);
+    const long v = e / c4;
+    const int b = (int)(v / nb);
+    long w = v - (long)b * nb;
+    int x, y, z;
+    if (w < n1) {
+        const int zf = (int)(w / ((long)Y * X)); const int rem = (int)(w - (long)zf * Y * X);
+        z = zf == 0 ? 0 : Z - 1; y = rem / X; x = rem - y * X;
+    } else if (w < n1 + n2) {
+        w -= n1;
+        const int zi = (int)(w / (nyf * X)); const int rem = (int)(w - (long)zi * nyf * X);
+        const int yf = rem / X;
+        z = 1 + zi; y = yf == 0 ? 0 : Y - 1; x = rem - yf * X;
+    } else {
+        w -= n1 + n2;
+        const int zi = (int)(w / (Yi * nxf)); const int rem = (int)(w - (long)zi * Yi * nxf);
+        const int yi = rem / nxf, xf = rem - yi * nxf;
+        z = 1 + zi; y = 1 + yi; x = xf == 0 ? 0 : X - 1;
+    }
+    const int PZ = Z + lz + hz, PY = Y + ly + hy, PX = X + lx + hx;
+    const int z0 = z == 0 ? 0 : z + lz, z1 = z == Z - 1 ? PZ - 1 : z + lz;
+    const int y0 = y == 0 ? 0 : y + ly, y1 = y == Y - 1 ? PY - 1 : y + ly;
+    const int x0 = x == 0 ? 0 : x + lx, x1 = x == X - 1 ? PX - 1 : x + lx;
+    if (z0 == z1 && y0 == y1 && x0 == x1) return;          // nothing clamps to it
+    float *own = dx + ((((long)b * Z + z) * Y + y) * X + x) * c + 4 * k4;
+    f32x4 s = *(const f32x4 *)own;
+    for (int pz = z0; pz <= z1; ++pz)
+        for (int py = y0; py <= y1; ++py)
+            for (int px = x0; px <= x1; ++px)
+                if (pz != z + lz || py != y + ly || px != x + lx)
+                    s += *(const f32x4 *)(dxp + ((((long)b * PZ + pz) * PY + py) * PX + px) * c + 4 * k4);
+    *(f32x4 *)own = s;
+}
+
 extern "C" int urn_dense_fold(const float *dxp, float *dx, int batch, const int *dims /* Z, Y, X */, const int *pad_lo,
                               const int *pad_hi, int c, void *stream)
 {
@@ -799,6 +865,33 @@ extern "C" int urn_dense_fold(const float *dxp, float *dx, int batch, const int 
     if (total == 0) return URN_OK;
     hipLaunchKernelGGL(k_dense_fold, dim3(urn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dxp, dx, batch, dims[0], dims[1],
                        dims[2], pad_lo[0], pad_hi[0], pad_lo[1], pad_hi[1], pad_lo[2], pad_hi[2], c);
+    URN_LAUNCH_CHECK();
+    return URN_OK;
+}
+
+// Input gradient of a stride-1 convolution on the replicate-padded volume AND its un-padding: urn_dense_conv with the
+// geometry of the padded volume (gm) into dxp, then urn_dense_fold into dx -- but when the launch is the 3 x 3 x 3 fast
+// path the kernel writes the voxels inside the volume straight to dx and only the shell to dxp, and the fold touches the
+// boundary voxels only (128^3 x 16: 55 us of fold -> 8).  Same results, same order of the sums at the boundary voxels
+// except that a voxel's own position comes first.
+extern "C" int urn_dense_conv_dgrad_fold(const float *dy, int64_t ld_dy, int cout, const float *wb, float *dxp, float *dx, int64_t ld_dx,
+                                         int cin, int batch, const urn_dense_geom *gm, const int *dims, const int *pad_lo,
+                                         const int *pad_hi, int precision, void *scratch, int64_t scratch_bytes, void *stream)
+{
+    URN_CHECK_ARG(dy && wb && dxp && dx && gm && dims && pad_lo && pad_hi, "null pointer");
+    g_fold.armed = true; g_fold.used = false; g_fold.y = dx;
+    for (int d = 0; d < 3; ++d) { g_fold.lo[d] = pad_lo[d]; g_fold.in[d] = dims[d]; }
+    const int r = urn_dense_conv(dy, ld_dy, cout, wb, nullptr, dxp, ld_dx, cin, batch, gm, precision, nullptr, 0, nullptr, nullptr, scratch,
+                                 scratch_bytes, stream);
+    g_fold.armed = false;
+    if (r != URN_OK) return r;
+    if (!g_fold.used) return urn_dense_fold(dxp, dx, batch, dims, pad_lo, pad_hi, cin, stream);
+    URN_CHECK_ARG(ld_dx == cin, "dense rows");
+    const long Zd = dims[0], Yd = dims[1], Xd = dims[2];
+    const long nbnd = (Zd < 2 ? Zd : 2) * Yd * Xd + (Zd > 2 ? Zd - 2 : 0) * ((Yd < 2 ? Yd : 2) * Xd + (Yd > 2 ? Yd - 2 : 0) * (Xd < 2 ? Xd : 2));
+    const long total = (long)batch * nbnd * (cin / 4);
+    hipLaunchKernelGGL(k_dense_fold_border, dim3(urn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float *)dxp, dx, batch, dims[0],
+                       dims[1], dims[2], pad_lo[0], pad_hi[0], pad_lo[1], pad_hi[1], pad_lo[2], pad_hi[2], cin);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }
@@ -1126,45 +1219,59 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
     }
 }
 
-__global__ void k_dense_dw_reduce(const float *__restrict__ slab, int S, long n, float *__restrict__ dw)
+// Sum of the S partial slabs, 4 consecutive elements per thread.  The narrow layers have few elements and many partials
+// (128^3 x 16 -> 16: 6,912 weights, 512 slabs = 14 MB): with one thread per 4 elements summing all the slabs that was 7
+// workgroups each walking 512 dependent-latency steps, 25 us per convolution and 1.2 ms per cfg2 step.  So the slabs are
+// dealt to SL slices of the workgroup as well (thread = (element quad, slice); slice j takes slabs j, j + SL, ...: eight
+// loads in flight), and the SL slice sums are combined through LDS in the fixed order 0 .. SL-1: the result depends on
+// the launch shape only, bitwise reproducible.  SL is a power of two <= 64 chosen by the host from n (1 for the big layers).
+__device__ __forceinline__ f32x4 dense_dw_sum(const float *__restrict__ slab, int S, long n, long e, int SL, bool ok, f32x4 *s_part)
 {
-    const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (e >= n) return;
+    const int EQ = 256 / SL, eq = threadIdx.x % EQ, sl = threadIdx.x / EQ;
     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 8 <= S; s += 8) {
-        f32x4 p[8];
+    if (ok) {
+        int s = sl;
+        for (; s + 7 * SL < S; s += 8 * SL) {
+            f32x4 p[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] = *(const f32x4 *)(slab + (long)(s + k) * n + e);
+            for (int k = 0; k < 8; ++k) p[k] = *(const f32x4 *)(slab + (long)(s + k * SL) * n + e);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += p[k];
+            for (int k = 0; k < 8; ++k) v += p[k];
+        }
+        for (; s < S; s += SL) v += *(const f32x4 *)(slab + (long)s * n + e);
     }
-    for (; s < S; ++s) v += *(const f32x4 *)(slab + (long)s * n + e);
-    *(f32x4 *)(dw + e) += v;
+    if (SL == 1) return v;
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    if (sl == 0)
+        for (int j = 1; j < SL; ++j) v += s_part[j * EQ + eq];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_dense_dw_reduce(const float *__restrict__ slab, int S, long n, float *__restrict__ dw, int SL)
+{
+    __shared__ f32x4 s_part[256];
+    const int EQ = 256 / SL;
+    const long e = ((long)blockIdx.x * EQ + threadIdx.x % EQ) * 4;
+    const f32x4 v = dense_dw_sum(slab, S, n, e, SL, e < n, s_part);
+    if (e < n && threadIdx.x / EQ == 0) *(f32x4 *)(dw + e) += v;
 }
 
 // the same sum written (not accumulated) in torch's parameter layout: element [tap][ix][iy] of the slab layout goes to
 // out[(iy * vx + ix) * ntap + tap] for ix < vx, iy < vy (the zero-padded channels are dropped) -- nn.Conv weight
 // (cout, cin, taps) with x = input, y = output channels, nn.ConvTranspose weight (cin, cout, taps) with the roles swapped.
-__global__ void k_dense_dw_reduce_t(const float *__restrict__ slab, int S, long n, int cx, int cy, int vx, int vy, int ntap,
-                                    float *__restrict__ out)
+__global__ __launch_bounds__(256) void k_dense_dw_reduce_t(const float *__restrict__ slab, int S, long n, int cx, int cy, int vx, int vy,
+                                                           int ntap, float *__restrict__ out, int SL)
 {
-    const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (e >= n) return;
+    __shared__ f32x4 s_part[256];
+    const int EQ = 256 / SL;
+    const long e = ((long)blockIdx.x * EQ + threadIdx.x % EQ) * 4;
     const int iy = (int)(e % cy);
     const long r = e / cy;
     const int ix = (int)(r % cx), tap = (int)(r / cx);
-    if (ix >= vx || iy >= vy) return;
-    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 8 <= S; s += 8) {
-        f32x4 p[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] = *(const f32x4 *)(slab + (long)(s + k) * n + e);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v += p[k];
-    }
-    for (; s < S; ++s) v += *(const f32x4 *)(slab + (long)s * n + e);
+    const bool ok = e < n && ix < vx && iy < vy;
+    const f32x4 v = dense_dw_sum(slab, S, n, e, SL, ok, s_part);
+    if (!ok || threadIdx.x / EQ != 0) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (iy + k < vy) out[((long)(iy + k) * vx + ix) * ntap + tap] = v[k];
@@ -1244,11 +1351,15 @@ extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *d
         if (precision) hipLaunchKernelGGL(k_dense_dw<1>, grid, block, lds, st, a);
         else hipLaunchKernelGGL(k_dense_dw<0>, grid, block, lds, st, a);
     }
+    // slices of the partial slabs per workgroup (see dense_dw_sum): enough threads for the chip, at most one slice per two slabs
+    int SL = 1;
+    while (SL < 64 && (n / 4) * SL < 131072 && 2 * SL * 2 <= S) SL *= 2;
+    const unsigned rgrid = (unsigned)urn_cdiv((n + 3) / 4, 256 / SL);
     if (dw_layout == 1)
-        hipLaunchKernelGGL(k_dense_dw_reduce_t, dim3(urn_cdiv((n + 3) / 4, 256)), dim3(256), 0, st, (const float *)scratch, (int)S, n, cin,
-                           cout, cin_valid, cout_valid, ntap, dw);
+        hipLaunchKernelGGL(k_dense_dw_reduce_t, dim3(rgrid), dim3(256), 0, st, (const float *)scratch, (int)S, n, cin,
+                           cout, cin_valid, cout_valid, ntap, dw, SL);
     else
-        hipLaunchKernelGGL(k_dense_dw_reduce, dim3(urn_cdiv((n + 3) / 4, 256)), dim3(256), 0, st, (const float *)scratch, (int)S, n, dw);
+        hipLaunchKernelGGL(k_dense_dw_reduce, dim3(rgrid), dim3(256), 0, st, (const float *)scratch, (int)S, n, dw, SL);
     URN_LAUNCH_CHECK();
     return URN_OK;
 }

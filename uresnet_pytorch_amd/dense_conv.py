@@ -309,15 +309,27 @@ class DenseConvFunction(torch.autograd.Function):
             n_p = B * Pd[0] * Pd[1] * Pd[2]
             full = stride == 1 or len(bwd) == 2 ** len(spatial)      # every padded position is written by some launch
             dxp = (torch.empty if full else torch.zeros)((n_p, cin_p), dtype=torch.float32, device=dy.device)
-            for g in bwd:
-                _launch(dy, cout_p, cout_p, wb, None, dxp, cin_p, cin_p, B, g)
-            if any(lo) or any(hi):
+            I3 = ctypes.c_int * 3
+            if stride == 1 and len(bwd) == 1 and (any(lo) or any(hi)):
+                # one call: the kernel writes the voxels inside the volume straight to dxf, the fold touches the boundary only
                 dxf = torch.empty((B * In[0] * In[1] * In[2], cin_p), dtype=torch.float32, device=dy.device)
-                I3 = ctypes.c_int * 3
-                _l.check(L.urn_dense_fold(dxp.data_ptr(), dxf.data_ptr(), B, I3(*In), I3(*lo), I3(*hi), cin_p, _l.stream()),
-                         'dense_fold')
+                sb = L.urn_dense_conv_scratch_bytes(cin_p, B, ctypes.byref(bwd[0]))
+                key = (dy.device, sb > 256)
+                scratch = _SCRATCH.get(key)
+                if scratch is None or scratch.numel() < sb:
+                    scratch = _SCRATCH[key] = torch.empty(max(sb, 256), dtype=torch.uint8, device=dy.device)
+                _l.check(L.urn_dense_conv_dgrad_fold(dy.data_ptr(), cout_p, cout_p, wb.data_ptr(), dxp.data_ptr(), dxf.data_ptr(), cin_p,
+                                                     cin_p, B, ctypes.byref(bwd[0]), I3(*In), I3(*lo), I3(*hi), PRECISION,
+                                                     scratch.data_ptr(), scratch.numel(), _l.stream()), 'dense_conv_dgrad_fold')
             else:
-                dxf = dxp
+                for g in bwd:
+                    _launch(dy, cout_p, cout_p, wb, None, dxp, cin_p, cin_p, B, g)
+                if any(lo) or any(hi):
+                    dxf = torch.empty((B * In[0] * In[1] * In[2], cin_p), dtype=torch.float32, device=dy.device)
+                    _l.check(L.urn_dense_fold(dxp.data_ptr(), dxf.data_ptr(), B, I3(*In), I3(*lo), I3(*hi), cin_p, _l.stream()),
+                             'dense_fold')
+                else:
+                    dxf = dxp
             dx = dxf[:, :cin].contiguous() if cin_p != cin else dxf
         if ctx.needs_input_grad[1]:
             dw = dense_conv_dw(xin, dy, weight.shape, B, spatial, stride, lo, Out, cin, cout, ctx.xfp)

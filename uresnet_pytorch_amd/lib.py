@@ -128,6 +128,8 @@ SIGNATURES = {
                              c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     'urn_dense_weight_layouts': (c_int, [c_int, c_void_p, c_void_p]),
     'urn_dense_fold': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'urn_dense_conv_dgrad_fold': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p]),
     'urn_dense_bn_act_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_int,
                                      c_void_p]),
     'urn_dense_bn_act_bwd_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
