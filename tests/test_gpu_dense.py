@@ -309,3 +309,39 @@ def test_trainer_dense_graph_flag_matches_eager(dev):
         assert len(rg['segmentation']) == 2 and rg['segmentation'][0].shape == re['segmentation'][0].shape
         assert rel(torch.from_numpy(rg['segmentation'][1]), torch.from_numpy(re['segmentation'][1])) < 1e-5
     assert rel(out[True][1], out[False][1]) < 1e-6
+
+
+def test_dense_zero_bias_gradients_survive_accumulation_and_in_place_writes(dev):
+    """The bias gradient of a convolution that a BatchNorm follows is exactly zero and comes out of ONE zero buffer
+    (dense_conv._ZeroGrads) instead of a fill launch per convolution.  A .grad that outlives its step -- two passes without
+    zero_grad, then zero_grad(set_to_none=False) -- must stay zero, never alias the statistics slabs of the next forward pass,
+    and an in-place write into one .grad must not leak into the next step's gradients."""
+    from types import SimpleNamespace
+    from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+    from uresnet_pytorch_amd.models import DenseUResNet, DenseSegmentationLoss
+    flags = SimpleNamespace(DATA_DIM=3, URESNET_FILTERS=16, URESNET_NUM_STRIDES=2, SPATIAL_SIZE=16, NUM_CLASS=5, BN_MOMENTUM=0.9)
+    torch.manual_seed(1)
+    net = DenseUResNet(flags).to(dev).train()
+    crit = DenseSegmentationLoss(flags)
+    blob = make_dense_blob([0, 1], 16, 3)
+    data = torch.from_numpy(blob['data']).to(dev); label = torch.from_numpy(blob['label']).to(dev)
+
+    def step():
+        loss, _ = crit(net(data), data, label, None)
+        loss.backward()
+    # the conv biases in front of a BatchNorm: every conv bias except the last layer's
+    names = [k for k, p in net.named_parameters() if k.endswith('.bias') and p.dim() == 1]
+    step(); step()                                   # accumulation: the second pass adds onto the first pass' .grad
+    grads = dict(net.named_parameters())
+    zero_biases = [k for k in names if grads[k].grad is not None and float(grads[k].grad.abs().max()) == 0.0]
+    assert len(zero_biases) >= 8, len(zero_biases)   # the convolutions that a BatchNorm follows
+    w_ref = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=False)                 # the .grad tensors stay alive ...
+    grads[zero_biases[0]].grad.add_(3.0)             # ... and someone writes into one in place
+    net.zero_grad(set_to_none=True)
+    step(); step()
+    for k, p in net.named_parameters():
+        if k in zero_biases:
+            assert float(p.grad.abs().max()) == 0.0, k
+        elif k in w_ref:
+            assert rel(p.grad, w_ref[k]) < 1e-5, k

@@ -77,10 +77,45 @@ _POOL = _ZeroPool()
 
 def pool_begin(device):
     _POOL.begin(device)
+    _ZGRADS.begin(device)
 
 
 def zeros_f64(shape, device):
     return _POOL.take(tuple(shape), device)
+
+
+class _ZeroGrads(object):
+    """The (exactly zero) bias gradient of a convolution that a BatchNorm follows -- ~60 per cfg2 step, a fill launch each
+    before: fresh views of ONE float buffer that nothing in this package ever writes except its own memset when a forward
+    pass begins (begin).  autograd's AccumulateGrad takes such a view over as .grad without a copy (or adds it to an older
+    view of the same zeros); the regions of a pass are distinct.  Deliberately NOT the statistics pool above: a .grad that
+    outlives the step (zero_grad(set_to_none=False), gradient accumulation over several passes) must not alias memory the
+    next forward pass accumulates sums in."""
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def begin(self, device):
+        if self.buf is not None and self.buf.device == device:
+            self.buf.zero_()          # (someone may have written into a .grad in place)
+        self.off = 0
+
+    def take(self, n, device):
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.zeros(1 << 16, dtype=torch.float32, device=device)
+            self.off = 0
+        if self.off + n > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        t = self.buf[self.off:self.off + n]
+        self.off += (n + 3) & ~3
+        return t
+
+
+_ZGRADS = _ZeroGrads()
+
+
+def zeros_f32(n, device):
+    return _ZGRADS.take(n, device)
 
 
 def new_stats(cout_p, device):
@@ -334,7 +369,7 @@ class DenseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = dense_conv_dw(xin, dy, weight.shape, B, spatial, stride, lo, Out, cin, cout, ctx.xfp)
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, cout) if ctx.bias_grad else torch.zeros(cout, dtype=torch.float32, device=dy.device)
+            db = _colsum(dy, cout) if ctx.bias_grad else zeros_f32(cout, dy.device)
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
@@ -419,5 +454,5 @@ class DenseConvTransposeFunction(torch.autograd.Function):
             lo = [1 if r else 0 for r in real]
             dw = _dw_call(dy, cout_p, xin, cin_p, B, Out, In, kk, ss, lo, 1, cout, cin, weight.shape)
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, cout) if ctx.bias_grad else torch.zeros(cout, dtype=torch.float32, device=dy.device)
+            db = _colsum(dy, cout) if ctx.bias_grad else zeros_f32(cout, dy.device)
         return dx, dw, db, None, None, None, None
