@@ -596,6 +596,7 @@ __global__ __launch_bounds__(256) void k_dense_splitk_reduce(DenseArgs g, int Z)
     }
 }
 
+int g_dense_strided_nrb = 16;          // row blocks per workgroup of the big strided launches (urn_set_option "dense_strided_nrb": 4 or 16; small launches drop to 4 below): cfg2 step 19.4 -> 19.2 ms
 long long *g_dense_stamps = nullptr;   // diagnostics (urn_set_option "dense_stamp_ptr"; kernels built with -DURN_DENSE_STAMP)
 
 // split factor of a launch: only when the output tiles alone leave most CUs idle
@@ -661,7 +662,15 @@ extern "C" int urn_dense_conv(const float *x, int64_t ldx, int cin, const float 
         TZ = nrb / TY;
         return (long)((a.Sub[2] + 15) / 16) * ((a.Sub[1] + TY - 1) / TY) * ((a.Sub[0] + TZ - 1) / TZ) * batch;
     };
-    a.NRB = strided ? 4 : 16; a.cw = 64;
+    a.NRB = 16; a.cw = 64;
+    if (strided) {
+        // 16 row blocks also for a strided input when the staged box (it grows with the stride) of ONE 16-channel chunk still fits
+        int ty, tz;
+        (void)tiles_for(16, ty, tz);
+        const long nbox16 = (long)(a.box[0] + a.s[0] * (tz - 1)) * (a.box[1] + a.s[1] * (ty - 1)) * (a.box[2] + a.s[2] * 15);
+        const long rowb1 = 16L * (precision ? 2 : 4) + 16;
+        if (g_dense_strided_nrb != 16 || ((nbox16 * rowb1 + 15) & ~15L) + (cout < 64 ? cout : 64) * rowb1 > 150L * 1024) a.NRB = 4;
+    }
     {
         int ty, tz;
         bool k333 = !strided;

@@ -313,6 +313,7 @@ extern int g_dw_pairs;
 extern int g_pairs_v3;
 extern int g_dw_2stage;
 extern long long *g_dense_stamps;
+extern int g_dense_strided_nrb;
 extern int g_net_wfrag, g_net_side2;
 extern int g_tile_rb, g_tile_cb, g_tile_kc, g_tile_depth, g_dw_blocks, g_tile_il, g_dw_kernel, g_dw_split, g_dw_group, g_tile_il_min_ks, g_tile_min_wgs, g_net_side_probe, g_net_side_verbose;
 static int g_opt_dbg = 0;
@@ -364,6 +365,7 @@ extern "C" int urn_set_option(const char *key, int64_t value)
     if (!strcmp(key, "dwp_waves")) { g_dwp_waves = (int)value; return URN_OK; }
     if (!strcmp(key, "dwp_smax")) { g_dwp_smax = value > 0 && value <= 256 ? (int)value : 16; return URN_OK; }
     if (!strcmp(key, "pairs_split")) { g_pairs_split = (int)value; return URN_OK; }
+    if (!strcmp(key, "dense_strided_nrb")) { g_dense_strided_nrb = value == 16 ? 16 : 4; return URN_OK; }
     if (!strcmp(key, "dense_stamp_ptr")) { g_dense_stamps = (long long *)(uintptr_t)value; return URN_OK; }
     if (!strcmp(key, "gconv_stamp_ptr")) { g_opt_stamps = (long long *)(uintptr_t)value; return URN_OK; }
     if (!strcmp(key, "gconv_dbg")) { g_opt_dbg = (int)value; return URN_OK; }
