@@ -1110,68 +1110,90 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
     // columns 4 (i & 3); plain reads (fp32): voxel 4m + q, channel r
     const int tr_row = 4 * q + (r >> 2), tr_col = 4 * (r & 3);
 
-    for (long tile = t_lo; tile < t_hi; ++tile) {
+    // Staging: the box (18 x 6 x 6 voxels, 16 NCI channels) and the dy tile (256 voxels, 16 NCO channels) of a tile as 16-byte
+    // pieces dealt flat over the 512 threads, ALL of a thread's loads requested before the first is parked (the row-per-wave
+    // loop this replaces waited for each box row before it asked for the next: five dependent round trips per tile, 13 us per
+    // tile at 128^3 x 16 -> 16 where the tile's MFMAs need 3).  With one channel block per side (PF) the requests of tile
+    // t + 1 go out BEFORE the MFMAs of tile t and are parked behind them: the round trip runs beside the arithmetic.
+    constexpr int PVX = 4 * NCI, PVY = 4 * NCO;                       // 16-byte pieces per voxel (fp32 source)
+    constexpr int BOX_E = NBOX * PVX, NITB = (BOX_E + 511) / 512;
+    constexpr int DY_E = 256 * PVY, NITD = (DY_E + 511) / 512;
+    constexpr bool PF = NCI * NCO == 1;
+    f32x4 vb[NITB], vd[NITD];
+    bool okb[NITB], okd[NITD];
+    auto issue = [&](long tile) {
         long t = tile;
         const int tx = (int)(t % tiles_x); t /= tiles_x;
         const int ty = (int)(t % tiles_y); t /= tiles_y;
         const int tz = (int)(t % tiles_z); const int b = (int)(t / tiles_z);
         const int ox0 = tx * 16, oy0 = ty * 4, oz0 = tz * 4;
         const int iz0 = oz0 - g.lo[0], iy0 = oy0 - g.lo[1], ix0 = ox0 - g.lo[2];
-        __syncthreads();
-        for (int rowi = wave; rowi < BZ * BY; rowi += 8) {
+#pragma unroll
+        for (int it = 0; it < NITB; ++it) {
+            const int e = it * 512 + tid;
+            const int vox = e / PVX, k4 = e - vox * PVX;
+            const int rowi = vox / BX, bx = vox - rowi * BX;
             const int bz = rowi / BY, by = rowi - bz * BY;
-            int iz = iz0 + bz, iy = iy0 + by;
-            bool okr = true;
-            if (g.mode == 0) { iz = min(max(iz, 0), g.In[0] - 1); iy = min(max(iy, 0), g.In[1] - 1); }
-            else { okr = iz >= 0 && iz < g.In[0] && iy >= 0 && iy < g.In[1]; if (!okr) { iz = 0; iy = 0; } }
-            const float *src_row = g.x + ((((long)b * g.In[0] + iz) * g.In[1] + iy) * g.In[2]) * g.ldx + ci0;
-            unsigned char *dst_row = s_box + rowi * BX * ROWB;
+            int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+            bool ok = e < BOX_E;
+            if (g.mode == 0) { iz = min(max(iz, 0), g.In[0] - 1); iy = min(max(iy, 0), g.In[1] - 1); ix = min(max(ix, 0), g.In[2] - 1); }
+            else if (iz < 0 || iz >= g.In[0] || iy < 0 || iy >= g.In[1] || ix < 0 || ix >= g.In[2]) { ok = false; }
+            if (!ok) { iz = 0; iy = 0; ix = 0; }
+            okb[it] = ok;
+            vb[it] = *(const f32x4 *)(g.x + ((((long)b * g.In[0] + iz) * g.In[1] + iy) * g.In[2] + ix) * g.ldx + ci0 + (ok ? 4 * k4 : 0));
+        }
 #pragma unroll
-            for (int it = 0; it < (BX * 8 + 63) / 64; ++it) {
-                const int e = it * 64 + lane;
-                if (e < BX * 8) {
-                    const int bx = e >> 3, k4 = e & 7;
-                    int ix = ix0 + bx;
-                    bool ok = okr && 4 * k4 < 16 * NCI;
-                    if (g.mode == 0) ix = min(max(ix, 0), g.In[2] - 1);
-                    else if (ix < 0 || ix >= g.In[2]) { ok = false; ix = 0; }
-                    f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (ok) val = dense_xf(*(const f32x4 *)(src_row + (long)ix * g.ldx + 4 * k4), g.xf_scale, g.xf_shift, ci0 + 4 * k4);
-                    if constexpr (PREC) {
-                        uint2 pk;
-                        pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
-                        *(uint2 *)(dst_row + bx * ROWB + 8 * k4) = pk;
-                    } else {
-                        *(f32x4 *)(dst_row + bx * ROWB + 16 * k4) = val;
-                    }
-                }
+        for (int it = 0; it < NITD; ++it) {
+            const int e = it * 512 + tid;
+            const int vox = e / PVY, k4 = e - vox * PVY;       // vox = rb * 16 + vx
+            const int rb = vox >> 4, vx = vox & 15;
+            const int oz = oz0 + (rb >> 2), oy = oy0 + (rb & 3), ox = ox0 + vx;
+            const bool ok = e < DY_E && oz < g.Out[0] && oy < g.Out[1] && ox < g.Out[2];
+            okd[it] = ok;
+            vd[it] = *(const f32x4 *)(g.dy + ((((long)b * g.Out[0] + (ok ? oz : 0)) * g.Out[1] + (ok ? oy : 0)) * g.Out[2] + (ok ? ox : 0)) * g.ld_dy + co0 + (ok ? 4 * k4 : 0));
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int it = 0; it < NITB; ++it) {
+            const int e = it * 512 + tid;
+            if (e >= BOX_E) continue;
+            const int vox = e / PVX, k4 = e - vox * PVX;
+            f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (okb[it]) val = dense_xf(vb[it], g.xf_scale, g.xf_shift, ci0 + 4 * k4);
+            unsigned char *dst = s_box + vox * ROWB;
+            if constexpr (PREC) {
+                uint2 pk;
+                pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
+                *(uint2 *)(dst + 8 * k4) = pk;
+            } else {
+                *(f32x4 *)(dst + 16 * k4) = val;
             }
         }
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int rb = wave + 8 * it;
-            const int oz = oz0 + (rb >> 2), oy = oy0 + (rb & 3);
-            const bool okr = oz < g.Out[0] && oy < g.Out[1];
-            const float *src_row = g.dy + ((((long)b * g.Out[0] + (okr ? oz : 0)) * g.Out[1] + (okr ? oy : 0)) * g.Out[2]) * g.ld_dy + co0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int e = h * 64 + lane;
-                const int vx = e >> 3, k4 = e & 7;
-                const int ox = ox0 + vx;
-                const bool ok = okr && ox < g.Out[2] && 4 * k4 < 16 * NCO;
-                f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok) val = *(const f32x4 *)(src_row + (long)ox * g.ld_dy + 4 * k4);
-                unsigned char *dst = s_dy + (rb * 16 + vx) * ROWB;
-                if constexpr (PREC) {
-                    uint2 pk;
-                    pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
-                    *(uint2 *)(dst + 8 * k4) = pk;
-                } else {
-                    *(f32x4 *)(dst + 16 * k4) = val;
-                }
+        for (int it = 0; it < NITD; ++it) {
+            const int e = it * 512 + tid;
+            if (e >= DY_E) continue;
+            const int vox = e / PVY, k4 = e - vox * PVY;
+            const f32x4 val = okd[it] ? vd[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            unsigned char *dst = s_dy + vox * ROWB;
+            if constexpr (PREC) {
+                uint2 pk;
+                pk.x = f2bf(val[0]) | ((unsigned)f2bf(val[1]) << 16); pk.y = f2bf(val[2]) | ((unsigned)f2bf(val[3]) << 16);
+                *(uint2 *)(dst + 8 * k4) = pk;
+            } else {
+                *(f32x4 *)(dst + 16 * k4) = val;
             }
         }
+    };
+    if (PF && t_lo < t_hi) issue(t_lo);
+    for (long tile = t_lo; tile < t_hi; ++tile) {
+        if (!PF) issue(tile);
+        __syncthreads();                      // the previous tile's readers are done with the box and the dy tile
+        park();
         __syncthreads();
+        if (PF && tile + 1 < t_hi) issue(tile + 1);
+        __builtin_amdgcn_sched_barrier(0);    // (keep the requests in front of the MFMA loop)
 #pragma unroll 4
         for (int rb = 0; rb < 16; ++rb) {
             const int rbase = ((rb >> 2) * BY + (rb & 3)) * BX;
