@@ -1118,10 +1118,10 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
     constexpr int PVX = 4 * NCI, PVY = 4 * NCO;                       // 16-byte pieces per voxel (fp32 source)
     constexpr int BOX_E = NBOX * PVX, NITB = (BOX_E + 511) / 512;
     constexpr int DY_E = 256 * PVY, NITD = (DY_E + 511) / 512;
-    constexpr bool PF = NCI * NCO == 1;
+    constexpr bool PF = NCI * NCO <= 2;
     f32x4 vb[NITB], vd[NITD];
     bool okb[NITB], okd[NITD];
-    auto issue = [&](long tile) {
+    auto issue = [&](long tile, int b_lo, int b_hi, bool with_dy) {   // (literal ranges at the call sites: resolved when unrolled)
         long t = tile;
         const int tx = (int)(t % tiles_x); t /= tiles_x;
         const int ty = (int)(t % tiles_y); t /= tiles_y;
@@ -1130,6 +1130,7 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
         const int iz0 = oz0 - g.lo[0], iy0 = oy0 - g.lo[1], ix0 = ox0 - g.lo[2];
 #pragma unroll
         for (int it = 0; it < NITB; ++it) {
+            if (it < b_lo || it >= b_hi) continue;
             const int e = it * 512 + tid;
             const int vox = e / PVX, k4 = e - vox * PVX;
             const int rowi = vox / BX, bx = vox - rowi * BX;
@@ -1144,6 +1145,7 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
         }
 #pragma unroll
         for (int it = 0; it < NITD; ++it) {
+            if (!with_dy) continue;
             const int e = it * 512 + tid;
             const int vox = e / PVY, k4 = e - vox * PVY;       // vox = rb * 16 + vx
             const int rb = vox >> 4, vx = vox & 15;
@@ -1153,9 +1155,10 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
             vd[it] = *(const f32x4 *)(g.dy + ((((long)b * g.Out[0] + (ok ? oz : 0)) * g.Out[1] + (ok ? oy : 0)) * g.Out[2] + (ok ? ox : 0)) * g.ld_dy + co0 + (ok ? 4 * k4 : 0));
         }
     };
-    auto park = [&]() {
+    auto park = [&](int b_lo, int b_hi, bool with_dy) {
 #pragma unroll
         for (int it = 0; it < NITB; ++it) {
+            if (it < b_lo || it >= b_hi) continue;
             const int e = it * 512 + tid;
             if (e >= BOX_E) continue;
             const int vox = e / PVX, k4 = e - vox * PVX;
@@ -1172,6 +1175,7 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
         }
 #pragma unroll
         for (int it = 0; it < NITD; ++it) {
+            if (!with_dy) continue;
             const int e = it * 512 + tid;
             if (e >= DY_E) continue;
             const int vox = e / PVY, k4 = e - vox * PVY;
@@ -1186,13 +1190,17 @@ __global__ __launch_bounds__(512) void k_dense_dw3(DenseDwArgs g)
             }
         }
     };
-    if (PF && t_lo < t_hi) issue(t_lo);
+    constexpr int HB = NITB > 8 ? 8 : NITB;   // wide tiles (two channel blocks on both sides): two batches per tile instead of 15 loads held
+    if (PF && t_lo < t_hi) issue(t_lo, 0, NITB, true);
     for (long tile = t_lo; tile < t_hi; ++tile) {
-        if (!PF) issue(tile);
         __syncthreads();                      // the previous tile's readers are done with the box and the dy tile
-        park();
+        if constexpr (PF) park(0, NITB, true);
+        else {
+            issue(tile, 0, HB, HB == NITB); park(0, HB, HB == NITB);
+            if constexpr (HB < NITB) { issue(tile, HB, NITB, true); park(HB, NITB, true); }
+        }
         __syncthreads();
-        if (PF && tile + 1 < t_hi) issue(tile + 1);
+        if (PF && tile + 1 < t_hi) issue(tile + 1, 0, NITB, true);
         __builtin_amdgcn_sched_barrier(0);    // (keep the requests in front of the MFMA loop)
 #pragma unroll 4
         for (int rb = 0; rb < 16; ++rb) {
