@@ -6,6 +6,8 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 from uresnet_pytorch_amd.iotools.synthetic import make_dense_blob
+from uresnet_pytorch_amd import lib as L_
+if os.environ.get('URN_LIB_PATH'): L_.LIB_PATH = os.environ['URN_LIB_PATH']   # an alternative build of the library (A/B of compile-time choices)
 from uresnet_pytorch_amd.models import DenseUResNet, DenseSegmentationLoss
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
