@@ -1316,6 +1316,37 @@ __global__ __launch_bounds__(256) void k_dense_dw_reduce_t(const float *__restri
         if (iy + k < vy) out[((long)(iy + k) * vx + ix) * ntap + tap] = v[k];
 }
 
+// The same for the wide layers (few slabs, many weights: 256 x 256 x 27 at 8^3), where the sum is cheap and the WRITE was the
+// cost: a thread's four iy values land 27 vx floats apart in torch's layout (78 us for 1.8 M weights).  A workgroup takes a
+// 16 (ix) x 16 (iy) block of all taps: reads 64-byte runs of iy, transposes through LDS, writes runs of 16 x ntap floats.
+__global__ __launch_bounds__(256) void k_dense_dw_reduce_tt(const float *__restrict__ slab, int S, long n, int cx, int cy, int vx, int vy,
+                                                            int ntap, float *__restrict__ out)
+{
+    __shared__ float s_t[27][16][17];
+    const int nby = cy / 16;
+    const int ix0 = (blockIdx.x / nby) * 16, iy0 = (blockIdx.x % nby) * 16;
+    const int tid = threadIdx.x, ixl = tid >> 4, iyl = tid & 15;
+    for (int tap = 0; tap < ntap; ++tap) {
+        const long e = ((long)tap * cx + ix0 + ixl) * cy + iy0 + iyl;
+        float v = 0.f;
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {
+            const float a = slab[(long)s * n + e], b = slab[(long)(s + 1) * n + e], c = slab[(long)(s + 2) * n + e], d = slab[(long)(s + 3) * n + e];
+            v += a; v += b; v += c; v += d;
+        }
+        for (; s < S; ++s) v += slab[(long)s * n + e];
+        s_t[tap][ixl][iyl] = v;
+    }
+    __syncthreads();
+    const int row_e = 16 * ntap;                       // floats of one iy row of the block in the output: [ix 16][tap]
+    for (int e = tid; e < 16 * row_e; e += 256) {
+        const int yl = e / row_e, rem = e - yl * row_e;
+        const int xl = rem / ntap, tap = rem - xl * ntap;
+        const int ix = ix0 + xl, iy = iy0 + yl;
+        if (ix < vx && iy < vy) out[((long)iy * vx + ix) * ntap + tap] = s_t[tap][xl][yl];
+    }
+}
+
 extern "C" int64_t urn_dense_dw_scratch_bytes(int batch, const int *out_dims, const int *k, int cin, int cout)
 {
     if (!out_dims || !k || cin <= 0 || cout <= 0) return -1;
@@ -1394,7 +1425,10 @@ extern "C" int urn_dense_dw(const float *x, int64_t ldx, int cin, const float *d
     int SL = 1;
     while (SL < 64 && (n / 4) * SL < 131072 && 2 * SL * 2 <= S) SL *= 2;
     const unsigned rgrid = (unsigned)urn_cdiv((n + 3) / 4, 256 / SL);
-    if (dw_layout == 1)
+    if (dw_layout == 1 && SL == 1 && ntap <= 27 && (long)cin * cout >= 64 * 64)
+        hipLaunchKernelGGL(k_dense_dw_reduce_tt, dim3((cin / 16) * (cout / 16)), dim3(256), 0, st, (const float *)scratch, (int)S, n, cin,
+                           cout, cin_valid, cout_valid, ntap, dw);
+    else if (dw_layout == 1)
         hipLaunchKernelGGL(k_dense_dw_reduce_t, dim3(rgrid), dim3(256), 0, st, (const float *)scratch, (int)S, n, cin,
                            cout, cin_valid, cout_valid, ntap, dw, SL);
     else
