@@ -841,6 +841,20 @@ def test_reduced_precision_operands(dev, prec, tol_op, tol_net):
             assert 1e-6 < e < tol_op, e      # > 1e-6: the reduced-precision kernels really ran
         # the weight gradient on the compacted rule lists (two stages, no atomics) with the same operand rounding
         # (k_dw_pairs<.., PREC>: the four rules a lane loads are the four contraction slots of one 16-bit MFMA), bitwise reproducible
+        # a full-width weight-gradient tile (four input-channel blocks: wave w owns block w, urn_set_option "dw_rowmode") and
+        # paired weight fragments with several chunks (cin / 16 even)
+        for ci2, co2 in ((128, 80), (160, 32)):
+            x3 = rng.normal(size=(n, ci2)).astype(np.float32)
+            W3 = (rng.normal(size=(27, ci2, co2)) / np.sqrt(27 * ci2)).astype(np.float32)
+            dy3 = rng.normal(size=(n, co2)).astype(np.float32)
+            xt3 = torch.from_numpy(x3).to(dev).requires_grad_(True); Wt3 = torch.from_numpy(W3).to(dev).requires_grad_(True)
+            p3 = geo.pairs['nbr'][0]
+            y3 = so.GConvFunction.apply(xt3, Wt3, None, geo.nbr[0], geo.nbr[0], 1, geo.ld, n, n, p3, p3)
+            y3.backward(torch.from_numpy(dy3).to(dev))
+            dx3_ref, dW3_ref = orc.conv_bwd(x3, W3, ref.nbr[0], dy3, ref.nbr_inv[0])
+            for got, want in ((y3.detach(), orc.conv_fwd(x3, W3, ref.nbr[0])), (xt3.grad, dx3_ref), (Wt3.grad, dW3_ref)):
+                e = rel(got.cpu().numpy(), want)
+                assert 1e-6 < e < tol_op, (ci2, co2, e)
         so.set_deterministic_dw(True, 'pairs')
         try:
             p0 = geo.pairs['nbr'][0]
