@@ -155,10 +155,13 @@ class BNFoldFunction(torch.autograd.Function):
         ctx.save_for_backward(raw, gamma, f)
         scale, shift = f[2].clone(), f[3].clone()
         ctx.mark_non_differentiable(scale, shift)
+        ctx.set_materialize_grads(False)            # (autograd would hand backward() two freshly zero-filled (c,) tensors for them)
         return raw, scale, shift                    # the same rows: the consumer applies the affine map itself
 
     @staticmethod
     def backward(ctx, d_out, _ds, _dh):
+        if d_out is None:
+            return None, None, None, None, None
         raw, gamma, f = ctx.saved_tensors
         L = _l.load()
         n, c = raw.shape
@@ -254,10 +257,13 @@ class DenseCEFunction(torch.autograd.Function):
         ctx.save_for_backward(logits, label, data, row_lse, acc)
         ctx.w = weight
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
         return out[0].clone(), out
 
     @staticmethod
     def backward(ctx, gloss, _gout):
+        if gloss is None:
+            return None, None, None, None
         logits, label, data, row_lse, acc = ctx.saved_tensors
         L = _l.load()
         n, nc = logits.shape

@@ -461,10 +461,13 @@ class SegmentationCEFunction(torch.autograd.Function):
         ctx.save_for_backward(logits, data, label, row_lse, ev)
         ctx.w = w
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)      # (no zero tensor for the non-differentiable [loss, accuracy] pair: one fill launch per step)
         return out[0].clone(), out
-    
+
     @staticmethod
     def backward(ctx, gloss, _gout):
+        if gloss is None:
+            return None, None, None, None
         logits, data, label, row_lse, ev = ctx.saved_tensors
         L = _l.load()
         n, nc = logits.shape
