@@ -54,9 +54,12 @@ class trainval(object):
             overlap.arm(self._net, expected=self._n_trunk_fwd)
         self._n_trunk_fwd = 0
         if has_graph:
-            if scale != 1.0:
-                total_loss = total_loss * scale
-            total_loss.backward()
+            # the incoming gradient of the loss IS the scale: one cached scalar instead of a mul and a ones-fill launch per step
+            seeds = self.__dict__.setdefault('_loss_seeds', {})
+            key = (total_loss.device, total_loss.dtype, tuple(total_loss.shape), scale)
+            if key not in seeds:
+                seeds[key] = torch.full(tuple(total_loss.shape), scale, dtype=total_loss.dtype, device=total_loss.device)
+            total_loss.backward(seeds[key])
         if armed:
             self.last_collectives = overlap.finish()
         else:
