@@ -349,7 +349,8 @@ extern "C" int urn_tail_bwd(const float *dlogits, const float *x, const int32_t 
     URN_CHECK_ARG((m == 16 || m == 32) && nc > 0 && nc <= 8, "unsupported head shape (m 16 or 32, nc <= 8)");
     const int rpp = TAILB_THREADS / (m / 4);
     const long passes = urn_cdiv(n, rpp);
-    const long per_wg = urn_cdiv(passes, 1024);     // at most 1024 workgroups, each walking the same number of passes
+    // (every workgroup ends with nc * m float atomics onto the SAME addresses: 782 workgroups were 20 of the kernel's 26 us)
+    const long per_wg = urn_cdiv(passes, 192);      // at most 192 workgroups, each walking the same number of passes
     hipLaunchKernelGGL(k_tail_bwd, dim3((unsigned)urn_cdiv(passes, per_wg)), dim3(TAILB_THREADS), 0, (hipStream_t)stream, dlogits, x, row2site,
                        (long)n, m, nc, W, scale, shift, mean, invstd, gsite, dW, db, part, slots, n_sites == n ? 1 : 0);
     URN_LAUNCH_CHECK();
