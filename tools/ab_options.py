@@ -9,6 +9,7 @@ import numpy as np, torch
 from uresnet_pytorch_amd import lib as L_, parallel
 from uresnet_pytorch_amd.iotools.synthetic import make_sparse_blob
 from uresnet_pytorch_amd.models import SparseUResNet, SparseSegmentationLoss
+if os.environ.get('URN_LIB_PATH'): L_.LIB_PATH = os.environ['URN_LIB_PATH']   # an alternative build (compile-time choices)
 L = L_.load(); dev = torch.device('cuda:0')
 DEFAULTS = {'pairs_waves': 2560, 'pairs_wgs': 512, 'dw_blocks': 768, 'pairs_max_cin': 80, 'pairs_max_cout': 999,
             'pairs_nc': 0, 'pairs_split': 0, 'pairs_split_kc1': 0, 'pairs_split_kc2': 0, 'pairs_split_kc3': 0, 'pairs_split_kc4': 0, 'pairs_split_kc5': 0, 'pairs_cbg': 0, 'dw_split': 2, 'dw_2stage': 0, 'pairs_prec': 1, 'pairs_wgs16': 256, 'net_dbg_skip_dw': 0, 'pairs_waves_fwd': 0, 'pairs_v3': 0x17E, 'pairs_lds_cap16': 0, 'dw_pairs': 0, 'dw_rowmode': 1, 'dwp_cap': 2, 'dwp_waves': 2048, 'dwp_smax': 16}

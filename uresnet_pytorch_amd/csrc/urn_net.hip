@@ -16,6 +16,9 @@
 #include <vector>
 #include <chrono>
 
+#ifndef URN_SUM_SLOTS
+#define URN_SUM_SLOTS 8       // rows of an accumulated-statistics slab (every conv workgroup adds its column sums into row tile % slots); cfg3 step, builds A/B on one box: 4 rows 2.574 ms, 8 rows 2.504-2.515, 16 rows 2.556, 32 rows 2.653
+#endif
 int g_dw_group = 1;   // weight gradients per fork to the side stream (urn_set_option "dw_group"); measured: 1: 3.61 ms, 2: 3.66, 4: 3.64, 8: 3.74, 16: 3.85
 
 int g_net_wfrag = 1;       // fragment-ordered weight copies for the pair-list kernel (urn_set_option "net_wfrag")
@@ -463,7 +466,7 @@ struct urn_net {
     // accumulated statistics (default): conv epilogues add their column sums into [SUM_SLOTS][2][c] slabs carved
     // from one zeroed region per pass; the consuming kernels derive the BatchNorm coefficients themselves, so the
     // chain conv -> finalize -> conv loses its middle launch (94 launches per cfg3 step)
-    static constexpr int SUM_SLOTS = 8;
+    static constexpr int SUM_SLOTS = URN_SUM_SLOTS;
     int slab_stats = 0;                  // URN_NET_SLAB_STATS: per-workgroup slabs + finalize launches instead
     double *sums_base = nullptr;
     size_t sums_cap = 0, sums_off = 0;   // in doubles
