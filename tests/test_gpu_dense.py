@@ -43,6 +43,7 @@ CASES = [  # dim, spatial, cin, cout, k, stride
     (2, (16, 16), 16, 16, 3, 1), (2, (20, 12), 8, 32, 3, 2), (2, (16, 16), 32, 16, 1, 2), (2, (9, 17), 1, 8, 3, 1),
     (3, (8, 8, 8), 16, 16, 3, 1), (3, (8, 12, 16), 16, 32, 3, 2), (3, (8, 8, 8), 32, 64, 1, 2), (3, (4, 4, 4), 64, 48, 3, 1),
     (3, (6, 10, 20), 1, 16, 3, 1), (3, (8, 8, 8), 16, 5, 3, 1), (3, (16, 16, 16), 80, 16, 1, 1), (3, (5, 7, 9), 16, 16, 3, 2),
+    (3, (4, 4, 4), 64, 80, 3, 1),     # few slabs, >= 64 x 64 weights per tap: the LDS-transposing slab reduce (k_dense_dw_reduce_tt)
 ]
 
 
@@ -345,3 +346,32 @@ def test_dense_zero_bias_gradients_survive_accumulation_and_in_place_writes(dev)
             assert float(p.grad.abs().max()) == 0.0, k
         elif k in w_ref:
             assert rel(p.grad, w_ref[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 1e-5), ('bf16', 1e-2)])
+def test_dense_big_strided_launch(dev, prec, tol):
+    """A stride-2 convolution with >= 512 output tiles (4 x 64^3 x 16 -> 32^3 x 32): with bf16 operands the staged box of 16 row
+    blocks fits and the launch takes them (urn_dense.hip: dense_strided_nrb), with fp32 operands it keeps 4 -- both against
+    torch on the CPU, forward and both gradients."""
+    from uresnet_pytorch_amd import dense_conv as dc
+    dc.set_precision(prec)
+    try:
+        B, cin, cout, k, stride, spatial = 4, 16, 32, 3, 2, (64, 64, 64)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, cin, *spatial, generator=g)
+        w = torch.randn(cout, cin, k, k, k, generator=g) / (cin * k ** 3) ** 0.5
+        b = torch.randn(cout, generator=g)
+        lo, hi = ref_padding(k, stride, spatial[-1])
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y_ref = F.conv3d(F.pad(xr, (lo, hi) * 3, mode='replicate'), wr, b, stride=stride)
+        dy = torch.randn(y_ref.shape, generator=g)
+        y_ref.backward(dy)
+        rows = to_rows(x).to(dev).requires_grad_(True)
+        wg = w.to(dev).requires_grad_(True)
+        y = dc.DenseConvFunction.apply(rows, wg, b.to(dev), B, spatial, stride, lo, hi)
+        y.backward(to_rows(dy).to(dev))
+        assert rel(y, to_rows(y_ref)) < tol
+        assert rel(rows.grad, to_rows(xr.grad)) < tol
+        assert rel(wg.grad, wr.grad) < tol
+    finally:
+        dc.set_precision('fp32')
